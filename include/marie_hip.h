@@ -1,0 +1,114 @@
+/*
+ * marie_hip.h — C ABI of libmarie_hip.so, the MI355X (gfx950) OCR hot path.
+ *
+ * The reference (gregbugaj/marie-icr) has NO FFI on this path: its boundary is
+ * three Python abstract classes.  This header is the C boundary
+ * the Python mirrors of those classes (the marie_icr_amd Python package) bind with ctypes; each
+ * entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MHIP_E* code; nothing
+ *     throws across the ABI; mhip_last_error(ctx) holds the message.
+ *   - plain pointers and sizes only.  "_dev" pointers are device (HBM) addresses,
+ *     "_host" pointers are host addresses; the caller owns both.
+ *   - one ctx per (process, GPU); a ctx and its models are NOT thread-safe.
+ *   - device entry points enqueue on the ctx stream (mhip_set_stream) and return
+ *     without synchronising; *_host entry points synchronise before returning.
+ */
+#ifndef MARIE_HIP_H
+#define MARIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHIP_OK 0
+#define MHIP_EINVAL (-22)  /* bad argument / shape */
+#define MHIP_ENOMEM (-12)  /* device allocation failed */
+#define MHIP_EHIP (-5)     /* HIP runtime error (see mhip_last_error) */
+#define MHIP_ESTATE (-1)   /* call order violated (e.g. forward before finalize) */
+
+/* arithmetic type of the recognizer's conv/GEMM contractions */
+#define MHIP_PREC_F16 0 /* f16 operands, fp32 MFMA accumulate (v_mfma_f32_16x16x32_f16)   */
+#define MHIP_PREC_F32 1 /* exact fp32 operands and accumulate (v_mfma_f32_16x16x4_f32)    */
+
+typedef struct mhip_ctx mhip_ctx;
+typedef struct mhip_crnn mhip_crnn;
+
+/* ---- context ------------------------------------------------------------------------ */
+/* replaces: device selection in marie/models/utils.py:initialize_device_settings and the
+ * per-processor `.to(device)` calls (marie/document/craft_ocr_processor.py:142-146).     */
+int mhip_init(int device_id, mhip_ctx** out);
+int mhip_destroy(mhip_ctx* ctx);
+const char* mhip_last_error(mhip_ctx* ctx);
+/* hipStream_t to enqueue on (NULL = the null stream).  The caller keeps it alive. */
+int mhip_set_stream(mhip_ctx* ctx, void* hip_stream);
+int mhip_synchronize(mhip_ctx* ctx);
+/* "gfx950", CU count and HBM bytes of the bound device */
+int mhip_device_info(mhip_ctx* ctx, char* arch, size_t arch_len, int* cu_count, size_t* hbm_bytes);
+
+/* Per-kernel timing with HIP events on the ctx stream (bench.py's roofline leg).
+ * replaces: marie/logging_core/profile.py TimeContextCuda around model calls.
+ * While enabled every kernel launch is bracketed by an event pair; mhip_profile_read
+ * synchronises and returns the accumulated device time and launch count of one kernel id. */
+int mhip_profile_enable(mhip_ctx* ctx, int enable);
+int mhip_profile_reset(mhip_ctx* ctx);
+int mhip_profile_read(mhip_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+int mhip_kernel_count(void);
+const char* mhip_kernel_name(int kernel_id);
+
+/* ---- CRNN-family recognizer: None-VGG-BiLSTM-CTC ---------------------------------- */
+/* replaces: Model(opt) construction, marie/models/icr/model.py:27-68 (Trans=None, Feat=VGG,
+ * Seq=BiLSTM, Pred=CTC; imgH=32, input_channel=1, output_channel=512, hidden_size=256).  */
+int mhip_crnn_create(mhip_ctx* ctx, int precision, int num_class, mhip_crnn** out);
+int mhip_crnn_destroy(mhip_crnn* m);
+
+/* replaces: model.load_state_dict(torch.load(...)), marie/document/craft_ocr_processor.py:146.
+ * `key` is the reference state_dict key ("FeatureExtraction.ConvNet.0.weight", ... an optional
+ * "module." prefix is ignored); `data` is host fp32 in the checkpoint's own layout
+ * (conv: [Cout][Cin][kh][kw]; LSTM/Linear: [out][in]).  Unknown keys return MHIP_EINVAL,
+ * "num_batches_tracked" is accepted and ignored.                                          */
+int mhip_crnn_set_tensor(mhip_crnn* m, const char* key, const float* data_host, const int64_t* shape, int ndim);
+/* Repack every tensor into the kernels' layouts (NHWC taps, BN folded to scale/shift, LSTM
+ * gates in MFMA-fragment order) inside ONE device arena and upload it.  Fails with MHIP_ESTATE
+ * if any tensor is missing.                                                                */
+int mhip_crnn_finalize(mhip_crnn* m);
+/* Allocate the (identically laid out) arena without filling it — for ranks that receive the
+ * weights by an RCCL broadcast of the arena instead of reading a checkpoint.              */
+int mhip_crnn_alloc_arena(mhip_crnn* m);
+int mhip_crnn_arena(mhip_crnn* m, void** arena_dev, size_t* bytes);
+
+/* T (time steps) for a crop of width w: w/4 - 1 (VGG stack, imgH = 32). */
+int mhip_crnn_seq_len(int w);
+
+/* Forward + greedy CTC decode of n pre-cropped grayscale lines, all 32 x w (w % 4 == 0, w >= 8).
+ * replaces: AlignCollate's ToTensor/normalise for a full-width crop
+ * (marie/models/icr/dataset.py:275-283), model(image, text_for_pred)
+ * (marie/document/craft_ocr_processor.py:236-237), preds.max(2) (:240),
+ * CTCLabelConverter.decode (marie/models/icr/utils.py:41-54) and the confidence
+ * softmax/max/cumprod (:255-271).
+ *   crops_dev   uint8  [n][32][w]
+ *   logits_dev  fp32   [n][T][num_class]          or NULL
+ *   argmax_dev  int32  [n][T]      raw per-step argmax (first max on ties)
+ *   tokens_dev  int32  [n][T]      collapsed sequence (blank and repeats removed), 0-padded
+ *   lengths_dev int32  [n]         number of valid tokens per line
+ *   conf_dev    fp32   [n]         product over all T steps of the max softmax probability */
+int mhip_crnn_forward(mhip_crnn* m, const uint8_t* crops_dev, int n, int w, float* logits_dev,
+                      int32_t* argmax_dev, int32_t* tokens_dev, int32_t* lengths_dev, float* conf_dev);
+/* Same with host buffers: H2D of the crops, forward, D2H of the outputs, stream sync. */
+int mhip_crnn_forward_host(mhip_crnn* m, const uint8_t* crops_host, int n, int w, float* logits_host,
+                           int32_t* argmax_host, int32_t* tokens_host, int32_t* lengths_host,
+                           float* conf_host);
+/* Bytes of ctx workspace one forward of n lines of width w needs (activations, gate buffers). */
+size_t mhip_crnn_workspace_bytes(mhip_crnn* m, int n, int w);
+/* Algorithmic FLOPs (2*MAC) of one forward of n lines of width w, per kernel id — what
+ * bench.py divides by the measured kernel time for the roofline line.                    */
+double mhip_crnn_kernel_flops(mhip_crnn* m, int kernel_id, int n, int w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARIE_HIP_H */

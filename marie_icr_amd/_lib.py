@@ -1,0 +1,128 @@
+"""ctypes binding of libmarie_hip.so (the C ABI declared in include/marie_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call
+fails, the product path raises.  Build it with ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C marie_icr_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmarie_hip.so")
+
+PREC_F16 = 0
+PREC_F32 = 1
+
+# every symbol include/marie_hip.h declares: (name, restype, argtypes)
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_SIGNATURES = (
+    ("mhip_init", _i, [_i, C.POINTER(_vp)]),
+    ("mhip_destroy", _i, [_vp]),
+    ("mhip_last_error", C.c_char_p, [_vp]),
+    ("mhip_set_stream", _i, [_vp, _vp]),
+    ("mhip_synchronize", _i, [_vp]),
+    ("mhip_device_info", _i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)]),
+    ("mhip_profile_enable", _i, [_vp, _i]),
+    ("mhip_profile_reset", _i, [_vp]),
+    ("mhip_profile_read", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("mhip_kernel_count", _i, []),
+    ("mhip_kernel_name", C.c_char_p, [_i]),
+    ("mhip_crnn_create", _i, [_vp, _i, _i, C.POINTER(_vp)]),
+    ("mhip_crnn_destroy", _i, [_vp]),
+    ("mhip_crnn_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
+    ("mhip_crnn_finalize", _i, [_vp]),
+    ("mhip_crnn_alloc_arena", _i, [_vp]),
+    ("mhip_crnn_arena", _i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    ("mhip_crnn_seq_len", _i, [_i]),
+    ("mhip_crnn_forward", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_crnn_forward_host", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_crnn_workspace_bytes", _sz, [_vp, _i, _i]),
+    ("mhip_crnn_kernel_flops", C.c_double, [_vp, _i, _i, _i]),
+)
+EXPORTED_SYMBOLS = tuple(s[0] for s in _SIGNATURES)
+
+_lib = None
+
+
+class MarieHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmarie_hip.so and type every entry point.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MarieHipError(
+            f"{LIB_PATH} is missing — the HIP extension is not built; there is no CPU fallback "
+            "(run __graft_entry__.build() or `make -C marie_icr_amd/csrc`)")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in _SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, rc: int, what: str):
+    if rc != 0:
+        msg = load().mhip_last_error(ctx_handle)
+        raise MarieHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+class Context:
+    """One per (process, GPU).  reference counterpart: the `.to(device)` plumbing of
+    marie/document/craft_ocr_processor.py:142-146."""
+
+    def __init__(self, device_id: int = 0):
+        lib = load()
+        h = C.c_void_p()
+        rc = lib.mhip_init(int(device_id), C.byref(h))
+        if rc != 0 or not h.value:
+            raise MarieHipError(f"mhip_init(device={device_id}) failed ({rc}): no usable HIP device")
+        self.h = h
+        self.lib = lib
+        self.device_id = int(device_id)
+
+    def set_stream(self, stream_handle: int | None):
+        check(self.h, self.lib.mhip_set_stream(self.h, C.c_void_p(stream_handle or 0)), "mhip_set_stream")
+
+    def synchronize(self):
+        check(self.h, self.lib.mhip_synchronize(self.h), "mhip_synchronize")
+
+    def device_info(self):
+        arch = C.create_string_buffer(64)
+        cu = C.c_int()
+        hbm = C.c_size_t()
+        check(self.h, self.lib.mhip_device_info(self.h, arch, 64, C.byref(cu), C.byref(hbm)), "mhip_device_info")
+        return {"arch": arch.value.decode(), "cu_count": cu.value, "hbm_bytes": hbm.value}
+
+    def profile_enable(self, on: bool):
+        check(self.h, self.lib.mhip_profile_enable(self.h, 1 if on else 0), "mhip_profile_enable")
+
+    def profile_reset(self):
+        check(self.h, self.lib.mhip_profile_reset(self.h), "mhip_profile_reset")
+
+    def profile_read(self):
+        out = {}
+        for k in range(self.lib.mhip_kernel_count()):
+            ms = C.c_double()
+            n = C.c_int64()
+            check(self.h, self.lib.mhip_profile_read(self.h, k, C.byref(ms), C.byref(n)), "mhip_profile_read")
+            out[self.lib.mhip_kernel_name(k).decode()] = {"id": k, "total_ms": ms.value, "launches": n.value}
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.mhip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

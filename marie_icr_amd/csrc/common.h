@@ -1,0 +1,100 @@
+// common.h — shared host/device declarations for libmarie_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/marie_hip.h"
+
+// ------------------------------------------------------------------ kernel ids (profiling)
+enum MhipKernelId {
+  MHIP_K_CONV_FIRST = 0,  // u8 -> normalise -> conv3x3(1->64)+ReLU+maxpool2x2
+  MHIP_K_CONV_IGEMM = 1,  // NHWC implicit-GEMM conv / GEMM on MFMA, fused scale/bias/ReLU/pool
+  MHIP_K_LSTM_REC = 2,    // BiLSTM recurrence (persistent over T, batch-sliced)
+  MHIP_K_CTC_DECODE = 3,  // wave-shuffle argmax + softmax-max + collapse
+  MHIP_K_COUNT = 4
+};
+
+struct ProfSlot {
+  double total_ms = 0.0;
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct mhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // workspace (grown on demand, never inside a steady-state forward)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  void* zeros = nullptr;  // 4 KiB of zeros: source of padding taps for LDS-DMA loads
+  bool profiling = false;
+  ProfSlot prof[MHIP_K_COUNT];
+  std::vector<hipEvent_t> event_pool;
+};
+
+int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...);
+int mhip_ensure_workspace(mhip_ctx* ctx, size_t bytes);
+void mhip_prof_begin(mhip_ctx* ctx, int kid, hipEvent_t* e0);
+void mhip_prof_end(mhip_ctx* ctx, int kid, hipEvent_t e0);
+
+#define MHIP_HIP(ctx, call)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (call);                                                              \
+    if (_e != hipSuccess)                                                                \
+      return mhip_fail((ctx), MHIP_EHIP, "%s failed: %s (%s:%d)", #call,                 \
+                       hipGetErrorString(_e), __FILE__, __LINE__);                       \
+  } while (0)
+
+// RAII-less launch bracket: PROF_LAUNCH(ctx, kid, kernel<<<...>>>(...));
+#define PROF_LAUNCH(ctx, kid, ...)                    \
+  do {                                                \
+    hipEvent_t _e0 = nullptr;                         \
+    if ((ctx)->profiling) mhip_prof_begin((ctx), (kid), &_e0); \
+    __VA_ARGS__;                                      \
+    if ((ctx)->profiling) mhip_prof_end((ctx), (kid), _e0);    \
+  } while (0)
+
+// ------------------------------------------------------------------ conv / GEMM launcher
+// Implicit-GEMM convolution over NHWC activations:  out[m][n] = act( scale[n] * sum_k A[m][k] W[n][k] + bias[n] )
+// with A[m][k] = in[b][y+dy-pad][x+dx-pad][c], k = (dy*KW+dx)*Cin + c, and an optional max-pool
+// folded into the epilogue (rows are enumerated so that a pooling window is 4 / 2 consecutive m).
+enum PoolMode { POOL_NONE = 0, POOL_2x2 = 1, POOL_2x1 = 2 };
+
+struct ConvDesc {
+  const void* in = nullptr;     // [B][H][W][Cin]  element type T
+  const void* w = nullptr;      // [N][KH*KW*Cin]  element type T (K contiguous)
+  const float* scale = nullptr; // [N] or nullptr (= 1)
+  const float* bias = nullptr;  // [N] or nullptr (= 0)
+  void* out = nullptr;          // [B][Hp][Wp][N]  T, or fp32 if out_f32
+  int B = 0, H = 0, W = 0, Cin = 0;
+  int KH = 1, KW = 1, pad = 0;
+  int N = 0;
+  int pool = POOL_NONE;
+  int relu = 0;
+  int out_f32 = 0;
+};
+// precision: MHIP_PREC_F16 / MHIP_PREC_F32.  Returns 0 or negative error.
+int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d);
+double mhip_conv_flops(const ConvDesc& d);
+
+// first layer: u8 [B][H][W] -> normalise -> conv3x3 pad1 (1->64) + bias + ReLU + maxpool 2x2 -> [B][H/2][W/2][64] T
+int mhip_launch_conv_first(mhip_ctx* ctx, int precision, const uint8_t* crops, const float* w9x64,
+                           const float* bias64, void* out, int B, int H, int W);
+
+// BiLSTM recurrence.  xproj fp32 [B][T][2][4][256] (input projection incl. both biases),
+// wpack = W_hh of both directions in MFMA fragment order, hseq out [B][T][512] T.
+int mhip_launch_lstm_rec(mhip_ctx* ctx, int precision, const float* xproj, const void* wpack, void* hseq,
+                         int B, int T);
+size_t mhip_lstm_wpack_bytes(int precision);
+// host-side packing of W_hh (fwd, bwd: [1024][256] fp32, gate order i,f,g,o) into fragment order
+void mhip_lstm_pack_whh(int precision, const float* whh_fwd, const float* whh_bwd, void* dst);
+
+// greedy CTC decode
+int mhip_launch_ctc_decode(mhip_ctx* ctx, const float* logits, int n, int T, int C, int32_t* argmax,
+                           int32_t* tokens, int32_t* lengths, float* conf);
