@@ -49,6 +49,8 @@ int mhip_set_stream(mhip_ctx* ctx, void* hip_stream);
 int mhip_synchronize(mhip_ctx* ctx);
 /* "gfx950", CU count and HBM bytes of the bound device */
 int mhip_device_info(mhip_ctx* ctx, char* arch, size_t arch_len, int* cu_count, size_t* hbm_bytes);
+/* Device-to-device copy on the ctx stream (e.g. weight arena <-> an RCCL broadcast buffer). */
+int mhip_memcpy_dev(mhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 
 /* Per-kernel timing with HIP events on the ctx stream (bench.py's roofline leg).
  * replaces: marie/logging_core/profile.py TimeContextCuda around model calls.

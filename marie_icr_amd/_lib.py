@@ -24,6 +24,7 @@ _SIGNATURES = (
     ("mhip_set_stream", _i, [_vp, _vp]),
     ("mhip_synchronize", _i, [_vp]),
     ("mhip_device_info", _i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)]),
+    ("mhip_memcpy_dev", _i, [_vp, _vp, _vp, _sz]),
     ("mhip_profile_enable", _i, [_vp, _i]),
     ("mhip_profile_reset", _i, [_vp]),
     ("mhip_profile_read", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -100,6 +101,10 @@ class Context:
         hbm = C.c_size_t()
         check(self.h, self.lib.mhip_device_info(self.h, arch, 64, C.byref(cu), C.byref(hbm)), "mhip_device_info")
         return {"arch": arch.value.decode(), "cu_count": cu.value, "hbm_bytes": hbm.value}
+
+    def memcpy_dev(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        check(self.h, self.lib.mhip_memcpy_dev(self.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), int(nbytes)),
+              "mhip_memcpy_dev")
 
     def profile_enable(self, on: bool):
         check(self.h, self.lib.mhip_profile_enable(self.h, 1 if on else 0), "mhip_profile_enable")

@@ -86,6 +86,12 @@ extern "C" int mhip_device_info(mhip_ctx* ctx, char* arch, size_t arch_len, int*
   return MHIP_OK;
 }
 
+extern "C" int mhip_memcpy_dev(mhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return MHIP_EINVAL;
+  MHIP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return MHIP_OK;
+}
+
 int mhip_ensure_workspace(mhip_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return MHIP_OK;
   MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
