@@ -7,29 +7,41 @@
 //   out[m][n] = act( scale[n] * sum_k A[m][k] * W[n][k] + bias[n] ),   k = (dy*KW + dx)*Cin + c
 //
 // Design (MI355X-first, no im2col buffer ever exists in HBM):
-//   * 128x128 output tile per 256-thread workgroup (4 waves, 64x64 each, 4x4 MFMA 16x16 tiles).
+//   * 256x128 output tile per 512-thread workgroup: 8 waves as 4(M) x 2(N), 64x64 per wave =
+//     4x4 MFMA 16x16 tiles, two waves per SIMD so one wave's ds_reads hide under the other's MFMAs.
 //   * K is walked in 128-byte slices (64 f16 / 32 f32 channels of one filter tap).  Both operand
-//     slices go HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip): the A slice
-//     is a *gather* — each lane's source address is its output pixel shifted by the tap, or a zero
-//     page for padding — while the LDS image stays lane-linear.  Two LDS buffers, one barrier per
-//     slice; the next slice's DMA is in flight while the current one feeds the MFMAs.
+//     slices go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip): the A slice
+//     is a *gather* - each lane's source address is its output pixel shifted by the tap, or a zero
+//     page for padding - while the LDS image stays lane-linear.
+//   * 3-slot LDS ring (3 x 48 KiB): the DMA of slices t+1 and t+2 stays in flight ACROSS the
+//     barrier of slice t (raw s_barrier + counted s_waitcnt vmcnt(6), never vmcnt(0) in the loop),
+//     one barrier per slice.
 //   * LDS rows are 128 B; the 16-B slot index is XOR-swizzled with (row>>1)&7 on the SOURCE side
 //     and on the ds_read_b128 side (cdna guide rule 21) so the 16 rows of a fragment read hit 16
 //     distinct slots of the 256-B bank row.
 //   * Rows (m) are enumerated so that a max-pool window is 4 (2x2) or 2 (2x1) consecutive rows.
 //     In the 16x16 MFMA C layout a lane owns 4 consecutive rows of one column, so the pool is a
-//     max over the lane's own accumulator registers — no extra pass, no extra HBM traffic.
+//     max over the lane's own accumulator registers - no extra pass, no extra HBM traffic.
+//   * Epilogue: scale/bias/ReLU/pool in registers, tile transposed through the (now idle) LDS ring
+//     and written with 16-B-per-lane stores, 256/512 contiguous bytes per output pixel.
+//   * Workgroup ids are remapped so that the blocks resident on one XCD cover consecutive
+//     (m-tile, all n-tiles): the n-tiles of an m-tile share their gathered A rows through that
+//     XCD's L2, and vertically adjacent m-tiles share their halo rows.
 //   * f16 operands use v_mfma_f32_16x16x32_f16; the exact-fp32 parity mode uses
 //     v_mfma_f32_16x16x4_f32 on the same LDS image (k order permuted identically for A and W).
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, ROWB = 128, NTHREADS = 256;
-constexpr int TILE_BYTES = BM * ROWB;  // 16 KiB per operand slice
+constexpr int BM = 256, BN = 128, ROWB = 128, NTHREADS = 512, NSTAGE = 3;
+constexpr int A_BYTES = BM * ROWB;               // 32 KiB
+constexpr int B_BYTES = BN * ROWB;               // 16 KiB
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 48 KiB
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB (of 160 KiB per CU)
 
 struct IgemmArgs {
   const char* in;
@@ -46,6 +58,7 @@ struct IgemmArgs {
   int nslices;   // Ktot / (ROWB/sizeof(T))
   int cpt;       // slices per tap
   int relu, out_f32;
+  int mtiles, ntiles;
 };
 
 template <typename T>
@@ -101,6 +114,11 @@ __device__ __forceinline__ void decode_row(const IgemmArgs& p, int m, int& b, in
   }
 }
 
+template <typename OT>
+__device__ __forceinline__ void lds_put(char* base, int pitch, int row, int col, float v) {
+  *(OT*)(base + row * pitch + col * (int)sizeof(OT)) = (OT)v;
+}
+
 template <typename T, int POOL>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,45 +127,58 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   constexpr int BKE = ROWB / sizeof(T);  // elements per K slice
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
-  // ---- staging set-up: each thread moves 4 A chunks + 4 W chunks per slice -------------
-  const int srow = wave * 8 + (lane >> 3);             // row within a 32-row group
+  // ---- XCD-aware tile assignment (bijective for any grid size; speed only) ---------------
+  int mt, nt;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    nt = L % p.ntiles;
+    mt = L / p.ntiles;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- staging set-up: each thread moves 4 A chunks + 2 W chunks per slice ---------------
+  const int srow = wave * 8 + (lane >> 3);             // row within a 64-row group
   const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);   // logical chunk this lane fetches
   const char* a_src[4];
   int a_y[4], a_x[4];
-  const char* w_src[4];
+  const char* w_src[2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    int m = m0 + q * 32 + srow;
+    int m = m0 + q * 64 + srow;
     int b = 0, y = -100000, x = -100000;  // invalid rows fail every bounds test
     if (m < p.M) decode_row<POOL>(p, m, b, y, x);
     a_y[q] = y;
     a_x[q] = x;
-    size_t pix = ((size_t)b * p.H + (y - p.pad)) * p.W + (x - p.pad);  // tap (0,0) position (may be OOB; guarded)
+    size_t pix = ((size_t)b * p.H + (y - p.pad)) * p.W + (x - p.pad);  // tap (0,0) position (guarded)
     a_src[q] = p.in + (pix * p.Cin + (size_t)lchunk * E) * sizeof(T);
-    int n = n0 + q * 32 + srow;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int n = n0 + q * 64 + srow;
     w_src[q] = (n < p.N) ? p.w + ((size_t)n * p.Ktot + (size_t)lchunk * E) * sizeof(T) : nullptr;
   }
 
-  auto stage = [&](int it, int buf) {
+  auto stage = [&](int it, int slot) {
     int tap = it / p.cpt, cc = it - tap * p.cpt;
     int dy = tap / p.KW, dx = tap - dy * p.KW;
     size_t a_off = (((size_t)dy * p.W + dx) * p.Cin + (size_t)cc * BKE) * sizeof(T);
     size_t w_off = (size_t)it * BKE * sizeof(T);
-    char* la = smem + buf * (2 * TILE_BYTES) + wave * 8 * ROWB;
-    char* lb = la + TILE_BYTES;
+    char* la = smem + slot * STAGE_BYTES + wave * 8 * ROWB;
+    char* lb = la + A_BYTES;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       int yy = a_y[q] + dy - p.pad, xx = a_x[q] + dx - p.pad;
       bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
       const char* src = ok ? a_src[q] + a_off : p.zeros;
-      glds16(src, la + q * 32 * ROWB);
+      glds16(src, la + q * 64 * ROWB);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
       const char* src = w_src[q] ? w_src[q] + w_off : p.zeros;
-      glds16(src, lb + q * 32 * ROWB);
+      glds16(src, lb + q * 64 * ROWB);
     }
   };
 
@@ -160,38 +191,58 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 
   const int wr = wave >> 1, wc = wave & 1;
   const int frow = lane & 15, fg = lane >> 4;
+  // per-lane LDS byte offsets of the two k-groups (constant across slices)
+  int a_off0[4], b_off0[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int ra = wr * 64 + t * 16 + frow;
+    a_off0[t] = ra * ROWB + ((fg ^ ((ra >> 1) & 7)) << 4);
+    int rb = wc * 64 + t * 16 + frow;
+    b_off0[t] = A_BYTES + rb * ROWB + ((fg ^ ((rb >> 1) & 7)) << 4);
+  }
 
+  // ---- main loop: 3-slot ring, 6 LDS-DMA instructions per wave per slice -----------------
   stage(0, 0);
+  if (p.nslices > 1) stage(1, 1);
+  int slot = 0, fill = 2;
   for (int it = 0; it < p.nslices; ++it) {
-    __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) and orders everyone's
-    if (it + 1 < p.nslices) stage(it + 1, (it + 1) & 1);
-    const char* sa = smem + (it & 1) * (2 * TILE_BYTES);
-    const char* sb = sa + TILE_BYTES;
+    if (it + 1 < p.nslices) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < p.nslices) stage(it + 2, fill);
+    const char* sb = smem + slot * STAGE_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       chunk_t a[4], b[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        int ra = wr * 64 + t * 16 + frow;
-        a[t] = *(const chunk_t*)(sa + ra * ROWB + (((s * 4 + fg) ^ ((ra >> 1) & 7)) << 4));
-        int rb = wc * 64 + t * 16 + frow;
-        b[t] = *(const chunk_t*)(sb + rb * ROWB + (((s * 4 + fg) ^ ((rb >> 1) & 7)) << 4));
+        // k-group s: logical chunk s*4+fg -> XOR with 4 flips bit 2 of the swizzled slot
+        a[t] = *(const chunk_t*)(sb + (a_off0[t] ^ (s << 6)));
+        b[t] = *(const chunk_t*)(sb + (b_off0[t] ^ (s << 6)));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) Tr<T>::mma(a[i], b[j], acc[i][j]);
     }
+    slot = (slot == NSTAGE - 1) ? 0 : slot + 1;
+    fill = (fill == NSTAGE - 1) ? 0 : fill + 1;
   }
 
-  // ---- epilogue: scale/bias, ReLU, in-register max-pool, store NHWC ---------------------
-  const int Mq = (POOL == POOL_2x2) ? (p.M >> 2) : (POOL == POOL_2x1) ? (p.M >> 1) : p.M;
+  // ---- epilogue: scale/bias, ReLU, in-register max-pool -> LDS -> coalesced NHWC stores ----
+  constexpr int PF = (POOL == POOL_2x2) ? 4 : (POOL == POOL_2x1) ? 2 : 1;
+  constexpr int RQ = BM / PF;  // output rows of this tile
+  const int Mq = p.M / PF;
+  const int q0 = m0 / PF;
+  const int oe = p.out_f32 ? 4 : (int)sizeof(T);
+  const int pitch = BN * oe + 16;
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    int n = n0 + wc * 64 + j * 16 + frow;
-    if (n >= p.N) continue;
-    float sc = p.scale ? p.scale[n] : 1.f;
-    float bi = p.bias ? p.bias[n] : 0.f;
+    const int lc = wc * 64 + j * 16 + frow;
+    const int n = n0 + lc;
+    const float sc = (p.scale && n < p.N) ? p.scale[n] : 1.f;
+    const float bi = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float v[4];
@@ -200,33 +251,47 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
         float t = acc[i][j][r] * sc + bi;
         v[r] = p.relu ? fmaxf(t, 0.f) : t;
       }
-      int mrow = m0 + wr * 64 + i * 16 + fg * 4;  // first of this lane's 4 consecutive rows
+      const int lr4 = wr * 64 + i * 16 + fg * 4;  // first of this lane's 4 consecutive tile rows
       if (POOL == POOL_2x2) {
-        int q = mrow >> 2;
-        if (q < Mq) {
-          float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-          size_t idx = (size_t)q * p.N + n;
-          if (p.out_f32) ((float*)p.out)[idx] = o; else ((T*)p.out)[idx] = (T)o;
-        }
+        float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (p.out_f32) lds_put<float>(smem, pitch, lr4 >> 2, lc, o);
+        else lds_put<T>(smem, pitch, lr4 >> 2, lc, o);
       } else if (POOL == POOL_2x1) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          int q = (mrow >> 1) + h;
-          if (q < Mq) {
-            float o = fmaxf(v[2 * h], v[2 * h + 1]);
-            size_t idx = (size_t)q * p.N + n;
-            if (p.out_f32) ((float*)p.out)[idx] = o; else ((T*)p.out)[idx] = (T)o;
-          }
+          float o = fmaxf(v[2 * h], v[2 * h + 1]);
+          if (p.out_f32) lds_put<float>(smem, pitch, (lr4 >> 1) + h, lc, o);
+          else lds_put<T>(smem, pitch, (lr4 >> 1) + h, lc, o);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int q = mrow + r;
-          if (q < Mq) {
-            size_t idx = (size_t)q * p.N + n;
-            if (p.out_f32) ((float*)p.out)[idx] = v[r]; else ((T*)p.out)[idx] = (T)v[r];
-          }
+          if (p.out_f32) lds_put<float>(smem, pitch, lr4 + r, lc, v[r]);
+          else lds_put<T>(smem, pitch, lr4 + r, lc, v[r]);
         }
+      }
+    }
+  }
+  __syncthreads();
+  const size_t grow = (size_t)p.N * oe;  // global bytes per output pixel
+  if ((grow & 15) == 0) {
+    const int cpr = BN * oe / 16;        // 16-B chunks per tile row
+    const int epc = 16 / oe;             // elements per chunk
+    for (int c = tid; c < RQ * cpr; c += NTHREADS) {
+      const int row = c / cpr, ch = c - row * cpr;
+      const int q = q0 + row, n = n0 + ch * epc;
+      if (q < Mq && n < p.N) {
+        uint4v val = *(const uint4v*)(smem + row * pitch + ch * 16);
+        *(uint4v*)(p.out + (size_t)q * grow + (size_t)n * oe) = val;
+      }
+    }
+  } else {  // ragged N (e.g. the 95-class prediction layer): element-wise
+    for (int e = tid; e < RQ * BN; e += NTHREADS) {
+      const int row = e / BN, col = e - row * BN;
+      const int q = q0 + row, n = n0 + col;
+      if (q < Mq && n < p.N) {
+        if (oe == 4) *(float*)(p.out + (size_t)q * grow + (size_t)n * 4) = *(const float*)(smem + row * pitch + col * 4);
+        else *(T*)(p.out + (size_t)q * grow + (size_t)n * sizeof(T)) = *(const T*)(smem + row * pitch + col * (int)sizeof(T));
       }
     }
   }
@@ -234,8 +299,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 
 template <typename T>
 int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
-  dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN), block(NTHREADS);
-  size_t lds = 4 * TILE_BYTES;
+  dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(NTHREADS);
+  size_t lds = LDS_BYTES;
   hipError_t e = hipSuccess;
   switch (pool) {
     case POOL_NONE:
@@ -300,9 +365,11 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.nslices = d.KH * d.KW * a.cpt;
   a.relu = d.relu;
   a.out_f32 = d.out_f32;
+  a.mtiles = (a.M + BM - 1) / BM;
+  a.ntiles = (a.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    size_t lds = 4 * TILE_BYTES;
+    size_t lds = LDS_BYTES;
 #define SETATTR(K) (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
     SETATTR((conv_igemm_kernel<_Float16, POOL_NONE>));
     SETATTR((conv_igemm_kernel<_Float16, POOL_2x2>));
