@@ -87,11 +87,14 @@ double mhip_conv_flops(const ConvDesc& d);
 int mhip_launch_conv_first(mhip_ctx* ctx, int precision, const uint8_t* crops, const float* w9x64,
                            const float* bias64, void* out, int B, int H, int W);
 
-// BiLSTM recurrence.  xproj fp32 [B][T][2][4][256] (input projection incl. both biases),
+// BiLSTM recurrence.  xproj fp32 [B][T][2][1024] with each direction's 1024 columns ordered
+// [wave][u][unit16][gate] (see mhip_lstm_xproj_row; input projection incl. both biases),
 // wpack = W_hh of both directions in MFMA fragment order, hseq out [B][T][512] T.
 int mhip_launch_lstm_rec(mhip_ctx* ctx, int precision, const float* xproj, const void* wpack, void* hseq,
                          int B, int T);
 size_t mhip_lstm_wpack_bytes(int precision);
+// PyTorch gate-matrix row that lands in (per-direction) xproj column `col` (gate-interleaved layout)
+int mhip_lstm_xproj_row(int col);
 // host-side packing of W_hh (fwd, bwd: [1024][256] fp32, gate order i,f,g,o) into fragment order
 void mhip_lstm_pack_whh(int precision, const float* whh_fwd, const float* whh_bwd, void* dst);
 

@@ -408,10 +408,14 @@ extern "C" int mhip_crnn_finalize(mhip_crnn* m) {
     for (int d = 0; d < 2; ++d)
       if (!wih[d] || !whh[d] || !bih[d] || !bhh[d]) return MHIP_ESTATE;
     if (!lw || !lb) return MHIP_ESTATE;
+    // rows permuted so the GEMM writes xproj gate-interleaved, the order lstm.hip consumes
     for (int d = 0; d < 2; ++d) {
-      put(m, h + L.ih_w[j] + (size_t)d * 1024 * in * es, wih[d]->data.data(), (size_t)1024 * in);
       float* bb = (float*)(h + L.ih_b[j]) + d * 1024;
-      for (int q = 0; q < 1024; ++q) bb[q] = bih[d]->data[q] + bhh[d]->data[q];
+      for (int col = 0; col < 1024; ++col) {
+        const int n = mhip_lstm_xproj_row(col);
+        put(m, h + L.ih_w[j] + ((size_t)d * 1024 + col) * in * es, wih[d]->data.data() + (size_t)n * in, (size_t)in);
+        bb[col] = bih[d]->data[n] + bhh[d]->data[n];
+      }
     }
     mhip_lstm_pack_whh(m->precision, whh[0]->data.data(), whh[1]->data.data(), h + L.hh_pack[j]);
     put(m, h + L.lin_w[j], lw->data.data(), (size_t)256 * 512);
