@@ -62,6 +62,22 @@ int mhip_profile_read(mhip_ctx* ctx, int kernel_id, double* total_ms, int64_t* l
 int mhip_kernel_count(void);
 const char* mhip_kernel_name(int kernel_id);
 
+/* ---- NHWC convolution / GEMM primitive -------------------------------------------------- */
+/* replaces: every nn.Conv2d (+ folded BatchNorm2d + ReLU + MaxPool2d) and nn.Linear on the path,
+ * e.g. marie/models/icr/modules/feature_extraction.py:13-25, marie/models/craft/craft.py:14-28,
+ * marie/models/craft/basenet/vgg16_bn.py:23-74.
+ *   out[b][yp][xp][n] = pool( act( scale[n] * sum_{dy,dx,c} in[b][y+dy-pad][x+dx-pad][c] * w[n][dy][dx][c] + bias[n] ) )
+ * in/w/out element type = precision (f16 or f32); out is fp32 when out_f32 != 0.  Stride 1, zero padding.
+ * Cin must be a multiple of 64 (f16) / 32 (f32).  pool: 0 none, 1 = 2x2/2 (floor), 2 = (2,1)/(2,1). */
+typedef struct mhip_conv_desc {
+  int32_t B, H, W, Cin; /* input  [B][H][W][Cin] */
+  int32_t KH, KW, pad;  /* filter [N][KH][KW][Cin] */
+  int32_t N;            /* output channels */
+  int32_t pool, relu, out_f32;
+} mhip_conv_desc;
+int mhip_conv2d_nhwc(mhip_ctx* ctx, int precision, const mhip_conv_desc* d, const void* in_dev,
+                     const void* w_dev, const float* scale_dev, const float* bias_dev, void* out_dev);
+
 /* ---- CRNN-family recognizer: None-VGG-BiLSTM-CTC ---------------------------------- */
 /* replaces: Model(opt) construction, marie/models/icr/model.py:27-68 (Trans=None, Feat=VGG,
  * Seq=BiLSTM, Pred=CTC; imgH=32, input_channel=1, output_channel=512, hidden_size=256).  */

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmarie_hip.so")
+# MARIE_HIP_LIB selects another build of the same library (kernel A/B experiments); never a fallback
+LIB_PATH = os.environ.get("MARIE_HIP_LIB") or os.path.join(_HERE, "libmarie_hip.so")
 
 PREC_F16 = 0
 PREC_F32 = 1
@@ -30,6 +31,7 @@ _SIGNATURES = (
     ("mhip_profile_read", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("mhip_kernel_count", _i, []),
     ("mhip_kernel_name", C.c_char_p, [_i]),
+    ("mhip_conv2d_nhwc", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mhip_crnn_create", _i, [_vp, _i, _i, C.POINTER(_vp)]),
     ("mhip_crnn_destroy", _i, [_vp]),
     ("mhip_crnn_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
@@ -43,6 +45,15 @@ _SIGNATURES = (
     ("mhip_crnn_kernel_flops", C.c_double, [_vp, _i, _i, _i]),
 )
 EXPORTED_SYMBOLS = tuple(s[0] for s in _SIGNATURES)
+
+
+
+class ConvDesc(C.Structure):
+    """mirror of ``mhip_conv_desc`` (include/marie_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "KH", "KW", "pad", "N", "pool", "relu", "out_f32")]
+
+
+POOL_NONE, POOL_2x2, POOL_2x1 = 0, 1, 2
 
 _lib = None
 
@@ -105,6 +116,14 @@ class Context:
     def memcpy_dev(self, dst_ptr: int, src_ptr: int, nbytes: int):
         check(self.h, self.lib.mhip_memcpy_dev(self.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), int(nbytes)),
               "mhip_memcpy_dev")
+
+    def conv2d_nhwc(self, precision: int, desc: "ConvDesc", in_ptr: int, w_ptr: int, scale_ptr: int, bias_ptr: int,
+                    out_ptr: int):
+        """Enqueue one NHWC conv/GEMM on the ctx stream; pointers are HBM addresses."""
+        check(self.h, self.lib.mhip_conv2d_nhwc(self.h, int(precision), C.byref(desc), C.c_void_p(in_ptr),
+                                                C.c_void_p(w_ptr), C.c_void_p(scale_ptr or 0),
+                                                C.c_void_p(bias_ptr or 0), C.c_void_p(out_ptr)),
+              "mhip_conv2d_nhwc")
 
     def profile_enable(self, on: bool):
         check(self.h, self.lib.mhip_profile_enable(self.h, 1 if on else 0), "mhip_profile_enable")

@@ -37,11 +37,28 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 256, BN = 128, ROWB = 128, NTHREADS = 512, NSTAGE = 3;
-constexpr int A_BYTES = BM * ROWB;               // 32 KiB
-constexpr int B_BYTES = BN * ROWB;               // 16 KiB
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 48 KiB
-constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB (of 160 KiB per CU)
+constexpr int BM = 256, ROWB = 128, NTHREADS = 512;
+constexpr int A_BYTES = BM * ROWB;  // 32 KiB
+
+// Two tile shapes share one kernel body:
+//   BN = 128: waves 4(M) x 2(N),  64x64 per wave, 3-slot ring of 48 KiB  (N <= 128)
+//   BN = 256: waves 2(M) x 4(N), 128x64 per wave, 2-slot ring of 64 KiB  (N  > 128): 1.5x fewer L2->LDS
+//             bytes and 25 % fewer LDS fragment reads per MFMA than the 128-wide tile.
+template <int BN_>
+struct Cfg {
+  static constexpr int BN = BN_;
+  static constexpr int WN = BN_ / 64;            // waves along N
+  static constexpr int WM = 8 / WN;              // waves along M
+  static constexpr int MT = BM / WM / 16;        // 16-row MFMA tiles per wave along M (4 or 8)
+  static constexpr int NSTAGE = (BN_ == 128) ? 3 : 2;
+  static constexpr int B_BYTES = BN_ * ROWB;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int WCHUNKS = BN_ / 64;       // W chunks staged per thread per slice
+  static constexpr int GL = 4 + WCHUNKS;         // LDS-DMA instructions per wave per slice
+  static constexpr int EPI_BYTES = BM * (128 * 4 + 16);  // one 128-column epilogue pass, fp32 worst case
+  static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
+  static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+};
 
 struct IgemmArgs {
   const char* in;
@@ -119,12 +136,14 @@ __device__ __forceinline__ void lds_put(char* base, int pitch, int row, int col,
   *(OT*)(base + row * pitch + col * (int)sizeof(OT)) = (OT)v;
 }
 
-template <typename T, int POOL>
+template <typename T, int POOL, int BN_>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Cfg<BN_> C;
   typedef typename Tr<T>::chunk_t chunk_t;
   constexpr int E = Tr<T>::E;            // elements per 16-B chunk
   constexpr int BKE = ROWB / sizeof(T);  // elements per K slice
+  constexpr int MT = C::MT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -137,14 +156,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     nt = L % p.ntiles;
     mt = L / p.ntiles;
   }
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = mt * BM, n0 = nt * C::BN;
 
-  // ---- staging set-up: each thread moves 4 A chunks + 2 W chunks per slice ---------------
+  // ---- staging set-up: each thread moves 4 A chunks + BN/64 W chunks per slice -----------
   const int srow = wave * 8 + (lane >> 3);             // row within a 64-row group
   const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);   // logical chunk this lane fetches
   const char* a_src[4];
   int a_y[4], a_x[4];
-  const char* w_src[2];
+  const char* w_src[C::WCHUNKS];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     int m = m0 + q * 64 + srow;
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     a_src[q] = p.in + (pix * p.Cin + (size_t)lchunk * E) * sizeof(T);
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < C::WCHUNKS; ++q) {
     int n = n0 + q * 64 + srow;
     w_src[q] = (n < p.N) ? p.w + ((size_t)n * p.Ktot + (size_t)lchunk * E) * sizeof(T) : nullptr;
   }
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     int dy = tap / p.KW, dx = tap - dy * p.KW;
     size_t a_off = (((size_t)dy * p.W + dx) * p.Cin + (size_t)cc * BKE) * sizeof(T);
     size_t w_off = (size_t)it * BKE * sizeof(T);
-    char* la = smem + slot * STAGE_BYTES + wave * 8 * ROWB;
+    char* la = smem + slot * C::STAGE_BYTES + wave * 8 * ROWB;
     char* lb = la + A_BYTES;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -176,147 +195,181 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       glds16(src, la + q * 64 * ROWB);
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < C::WCHUNKS; ++q) {
       const char* src = w_src[q] ? w_src[q] + w_off : p.zeros;
       glds16(src, lb + q * 64 * ROWB);
     }
   };
 
   // ---- accumulators ---------------------------------------------------------------------
-  float4v acc[4][4];
+  float4v acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / C::WN, wc = wave % C::WN;
   const int frow = lane & 15, fg = lane >> 4;
-  // per-lane LDS byte offsets of the two k-groups (constant across slices)
-  int a_off0[4], b_off0[4];
+  // per-lane LDS byte offsets of k-group 0 (k-group 1 = offset ^ 64)
+  int a_off0[MT], b_off0[4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int ra = wr * (MT * 16) + t * 16 + frow;
+    a_off0[t] = ra * ROWB + ((fg ^ ((ra >> 1) & 7)) << 4);
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    int ra = wr * 64 + t * 16 + frow;
-    a_off0[t] = ra * ROWB + ((fg ^ ((ra >> 1) & 7)) << 4);
     int rb = wc * 64 + t * 16 + frow;
     b_off0[t] = A_BYTES + rb * ROWB + ((fg ^ ((rb >> 1) & 7)) << 4);
   }
 
-  // ---- main loop: 3-slot ring, 6 LDS-DMA instructions per wave per slice -----------------
+  // ---- main loop: NSTAGE-slot ring, GL LDS-DMA instructions per wave per slice -----------
+  constexpr int D = C::NSTAGE - 1;  // slices in flight ahead of the one being computed
   stage(0, 0);
-  if (p.nslices > 1) stage(1, 1);
-  int slot = 0, fill = 2;
+  if (D > 1 && p.nslices > 1) stage(1, 1);
+  int slot = 0, fill = D % C::NSTAGE;
   for (int it = 0; it < p.nslices; ++it) {
-    if (it + 1 < p.nslices) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (D > 1 && it + 1 < p.nslices) {
+      if (C::GL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
-    if (it + 2 < p.nslices) stage(it + 2, fill);
-    const char* sb = smem + slot * STAGE_BYTES;
+#ifndef IGEMM_STAGE_LATE
+    if (it + D < p.nslices) stage(it + D, fill);
+#endif
+    const char* sb = smem + slot * C::STAGE_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      chunk_t a[4], b[4];
+      chunk_t a[MT], b[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        // k-group s: logical chunk s*4+fg -> XOR with 4 flips bit 2 of the swizzled slot
-        a[t] = *(const chunk_t*)(sb + (a_off0[t] ^ (s << 6)));
-        b[t] = *(const chunk_t*)(sb + (b_off0[t] ^ (s << 6)));
-      }
+      for (int t = 0; t < 4; ++t) b[t] = *(const chunk_t*)(sb + (b_off0[t] ^ (s << 6)));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int t = 0; t < MT; ++t) a[t] = *(const chunk_t*)(sb + (a_off0[t] ^ (s << 6)));
+#ifdef IGEMM_STAGE_LATE
+      // issue the refill of the slot freed at this barrier underneath the first k-group's MFMAs
+      if (s == 0 && it + D < p.nslices) stage(it + D, fill);
+#endif
+#ifndef IGEMM_NO_SETPRIO
+      __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster between the barriers (cdna guide T5)
+#endif
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) Tr<T>::mma(a[i], b[j], acc[i][j]);
+#ifndef IGEMM_NO_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
-    slot = (slot == NSTAGE - 1) ? 0 : slot + 1;
-    fill = (fill == NSTAGE - 1) ? 0 : fill + 1;
+    slot = (slot == C::NSTAGE - 1) ? 0 : slot + 1;
+    fill = (fill == C::NSTAGE - 1) ? 0 : fill + 1;
   }
 
   // ---- epilogue: scale/bias, ReLU, in-register max-pool -> LDS -> coalesced NHWC stores ----
+  // done in passes of 128 output columns so the staging tile fits next to nothing else in LDS
   constexpr int PF = (POOL == POOL_2x2) ? 4 : (POOL == POOL_2x1) ? 2 : 1;
   constexpr int RQ = BM / PF;  // output rows of this tile
   const int Mq = p.M / PF;
   const int q0 = m0 / PF;
   const int oe = p.out_f32 ? 4 : (int)sizeof(T);
-  const int pitch = BN * oe + 16;
-  __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int lc = wc * 64 + j * 16 + frow;
-    const int n = n0 + lc;
-    const float sc = (p.scale && n < p.N) ? p.scale[n] : 1.f;
-    const float bi = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = acc[i][j][r] * sc + bi;
-        v[r] = p.relu ? fmaxf(t, 0.f) : t;
-      }
-      const int lr4 = wr * 64 + i * 16 + fg * 4;  // first of this lane's 4 consecutive tile rows
-      if (POOL == POOL_2x2) {
-        float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        if (p.out_f32) lds_put<float>(smem, pitch, lr4 >> 2, lc, o);
-        else lds_put<T>(smem, pitch, lr4 >> 2, lc, o);
-      } else if (POOL == POOL_2x1) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float o = fmaxf(v[2 * h], v[2 * h + 1]);
-          if (p.out_f32) lds_put<float>(smem, pitch, (lr4 >> 1) + h, lc, o);
-          else lds_put<T>(smem, pitch, (lr4 >> 1) + h, lc, o);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (p.out_f32) lds_put<float>(smem, pitch, lr4 + r, lc, v[r]);
-          else lds_put<T>(smem, pitch, lr4 + r, lc, v[r]);
-        }
-      }
-    }
-  }
-  __syncthreads();
+  const int pitch = 128 * oe + 16;
   const size_t grow = (size_t)p.N * oe;  // global bytes per output pixel
-  if ((grow & 15) == 0) {
-    const int cpr = BN * oe / 16;        // 16-B chunks per tile row
-    const int epc = 16 / oe;             // elements per chunk
-    for (int c = tid; c < RQ * cpr; c += NTHREADS) {
-      const int row = c / cpr, ch = c - row * cpr;
-      const int q = q0 + row, n = n0 + ch * epc;
-      if (q < Mq && n < p.N) {
-        uint4v val = *(const uint4v*)(smem + row * pitch + ch * 16);
-        *(uint4v*)(p.out + (size_t)q * grow + (size_t)n * oe) = val;
+#pragma unroll
+  for (int pass = 0; pass < C::BN / 128; ++pass) {
+    __syncthreads();  // ring (or previous pass) fully consumed
+    if ((wc >> 1) == pass) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int lc = (wc & 1) * 64 + j * 16 + frow;
+        const int n = n0 + pass * 128 + lc;
+        const float sc = (p.scale && n < p.N) ? p.scale[n] : 1.f;
+        const float bi = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = acc[i][j][r] * sc + bi;
+            v[r] = p.relu ? fmaxf(t, 0.f) : t;
+          }
+          const int lr4 = wr * (MT * 16) + i * 16 + fg * 4;  // first of this lane's 4 consecutive tile rows
+          if (POOL == POOL_2x2) {
+            float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            if (p.out_f32) lds_put<float>(smem, pitch, lr4 >> 2, lc, o);
+            else lds_put<T>(smem, pitch, lr4 >> 2, lc, o);
+          } else if (POOL == POOL_2x1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              float o = fmaxf(v[2 * h], v[2 * h + 1]);
+              if (p.out_f32) lds_put<float>(smem, pitch, (lr4 >> 1) + h, lc, o);
+              else lds_put<T>(smem, pitch, (lr4 >> 1) + h, lc, o);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (p.out_f32) lds_put<float>(smem, pitch, lr4 + r, lc, v[r]);
+              else lds_put<T>(smem, pitch, lr4 + r, lc, v[r]);
+            }
+          }
+        }
       }
     }
-  } else {  // ragged N (e.g. the 95-class prediction layer): element-wise
-    for (int e = tid; e < RQ * BN; e += NTHREADS) {
-      const int row = e / BN, col = e - row * BN;
-      const int q = q0 + row, n = n0 + col;
-      if (q < Mq && n < p.N) {
-        if (oe == 4) *(float*)(p.out + (size_t)q * grow + (size_t)n * 4) = *(const float*)(smem + row * pitch + col * 4);
-        else *(T*)(p.out + (size_t)q * grow + (size_t)n * sizeof(T)) = *(const T*)(smem + row * pitch + col * (int)sizeof(T));
+    __syncthreads();
+    const int nbase = n0 + pass * 128;
+    if ((grow & 15) == 0) {
+      const int cpr = 128 * oe / 16;       // 16-B chunks per staged row
+      const int epc = 16 / oe;             // elements per chunk
+      for (int c = tid; c < RQ * cpr; c += NTHREADS) {
+        const int row = c / cpr, ch = c - row * cpr;
+        const int q = q0 + row, n = nbase + ch * epc;
+        if (q < Mq && n < p.N) {
+          uint4v val = *(const uint4v*)(smem + row * pitch + ch * 16);
+          *(uint4v*)(p.out + (size_t)q * grow + (size_t)n * oe) = val;
+        }
+      }
+    } else {  // ragged N (e.g. the 95-class prediction layer): element-wise
+      for (int e = tid; e < RQ * 128; e += NTHREADS) {
+        const int row = e >> 7, col = e & 127;
+        const int q = q0 + row, n = nbase + col;
+        if (q < Mq && n < p.N) {
+          if (oe == 4) *(float*)(p.out + (size_t)q * grow + (size_t)n * 4) = *(const float*)(smem + row * pitch + col * 4);
+          else *(T*)(p.out + (size_t)q * grow + (size_t)n * sizeof(T)) = *(const T*)(smem + row * pitch + col * (int)sizeof(T));
+        }
       }
     }
   }
 }
 
-template <typename T>
+template <typename T, int BN_>
 int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
   dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(NTHREADS);
-  size_t lds = LDS_BYTES;
-  hipError_t e = hipSuccess;
+  const size_t lds = Cfg<BN_>::LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, POOL_NONE, BN_>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, POOL_2x2, BN_>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, POOL_2x1, BN_>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   switch (pool) {
     case POOL_NONE:
       PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
-                  hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE>), grid, block, lds, ctx->stream, a));
+                  hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, BN_>), grid, block, lds, ctx->stream, a));
       break;
     case POOL_2x2:
       PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
-                  hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x2>), grid, block, lds, ctx->stream, a));
+                  hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x2, BN_>), grid, block, lds, ctx->stream, a));
       break;
     default:
       PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
-                  hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x1>), grid, block, lds, ctx->stream, a));
+                  hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x1, BN_>), grid, block, lds, ctx->stream, a));
       break;
   }
-  e = hipGetLastError();
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "conv_igemm launch: %s", hipGetErrorString(e));
   return 0;
 }
@@ -365,21 +418,10 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.nslices = d.KH * d.KW * a.cpt;
   a.relu = d.relu;
   a.out_f32 = d.out_f32;
+  const int bn = (a.N > 128) ? 256 : 128;
   a.mtiles = (a.M + BM - 1) / BM;
-  a.ntiles = (a.N + BN - 1) / BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    size_t lds = LDS_BYTES;
-#define SETATTR(K) (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-    SETATTR((conv_igemm_kernel<_Float16, POOL_NONE>));
-    SETATTR((conv_igemm_kernel<_Float16, POOL_2x2>));
-    SETATTR((conv_igemm_kernel<_Float16, POOL_2x1>));
-    SETATTR((conv_igemm_kernel<float, POOL_NONE>));
-    SETATTR((conv_igemm_kernel<float, POOL_2x2>));
-    SETATTR((conv_igemm_kernel<float, POOL_2x1>));
-#undef SETATTR
-    attr_set = true;
-  }
-  if (precision == MHIP_PREC_F16) return launch_t<_Float16>(ctx, a, d.pool);
-  return launch_t<float>(ctx, a, d.pool);
+  a.ntiles = (a.N + bn - 1) / bn;
+  if (precision == MHIP_PREC_F16)
+    return bn == 256 ? launch_t<_Float16, 256>(ctx, a, d.pool) : launch_t<_Float16, 128>(ctx, a, d.pool);
+  return bn == 256 ? launch_t<float, 256>(ctx, a, d.pool) : launch_t<float, 128>(ctx, a, d.pool);
 }

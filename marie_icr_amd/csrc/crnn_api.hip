@@ -166,6 +166,24 @@ extern "C" int mhip_profile_read(mhip_ctx* ctx, int kid, double* total_ms, int64
   return MHIP_OK;
 }
 
+// ======================================================================= conv primitive
+extern "C" int mhip_conv2d_nhwc(mhip_ctx* ctx, int precision, const mhip_conv_desc* d, const void* in,
+                                const void* w, const float* scale, const float* bias, void* out) {
+  if (!ctx || !d) return MHIP_EINVAL;
+  if (precision != MHIP_PREC_F16 && precision != MHIP_PREC_F32)
+    return mhip_fail(ctx, MHIP_EINVAL, "unknown precision %d", precision);
+  if (d->B < 1 || d->H < 1 || d->W < 1 || d->N < 1 || d->KH < 1 || d->KW < 1 || d->pad < 0 || d->pool < 0 ||
+      d->pool > 2)
+    return mhip_fail(ctx, MHIP_EINVAL, "conv2d: bad descriptor");
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  ConvDesc c;
+  c.in = in; c.w = w; c.scale = scale; c.bias = bias; c.out = out;
+  c.B = d->B; c.H = d->H; c.W = d->W; c.Cin = d->Cin;
+  c.KH = d->KH; c.KW = d->KW; c.pad = d->pad;
+  c.N = d->N; c.pool = d->pool; c.relu = d->relu; c.out_f32 = d->out_f32;
+  return mhip_launch_conv_igemm(ctx, precision, c);
+}
+
 // ======================================================================= CRNN model
 namespace {
 

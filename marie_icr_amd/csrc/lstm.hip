@@ -225,10 +225,9 @@ __global__ __launch_bounds__(256) void lstm_rec_stream(const float* __restrict__
                                                        const char* __restrict__ wpack, T* __restrict__ hseq,
                                                        int B, int Tn) {
   typedef typename Lt<T>::chunk_t chunk_t;
-  constexpr int E = Lt<T>::E;
+  [[maybe_unused]] constexpr int E = Lt<T>::E;
   constexpr int S = HID / (4 * E);           // k-groups per step (f16: 8, f32: 16)
   constexpr int ROWBYTES = HID * sizeof(T);  // 512 / 1024
-  static_assert(E == 4 || E == 8, "chunk width");
   __shared__ __attribute__((aligned(16))) char hbuf[2][ROWS * ROWBYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(256) void lstm_rec_stream(const float* __restrict__
         c[u][r] = cn;
         const float h = og * fast_tanh(cn);
         const int row = fg * 4 + r;
-        *(T*)(hn + row * ROWBYTES + ((((unit / E) ^ row)) << 4) + (unit % E) * sizeof(T)) = (T)h;
+        *(T*)(hn + row * ROWBYTES + ((((unit / E) ^ row)) << 4) + (unit % E) * sizeof(T)) = (T)h;  // E: elems per chunk
       }
     }
     __syncthreads();

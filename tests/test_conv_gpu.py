@@ -1,0 +1,83 @@
+"""conv_igemm through the C ABI vs a plain PyTorch fp32 reference of the same op (F.conv2d + scale/bias +
+ReLU + max_pool2d on CPU), over shapes that hit every tail: M not a multiple of 256, N not a multiple of 128,
+ragged N (95), odd widths, 2x2 valid filters, 1x1 GEMMs, both pooling modes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, H, W, Cin, KH, pad, N, pool, relu, out_f32
+    (2, 16, 32, 64, 3, 1, 128, 1, 1, 0),
+    (3, 8, 25, 128, 3, 1, 256, 0, 1, 0),     # odd width, M = 600 (tail)
+    (2, 8, 25, 64, 3, 1, 64, 2, 1, 0),       # N < 128, 2x1 pool
+    (1, 5, 7, 64, 3, 1, 192, 1, 0, 0),       # odd H and W with 2x2 floor pooling
+    (2, 2, 26, 128, 2, 0, 128, 0, 1, 0),     # 2x2 valid
+    (1, 1, 1, 256, 1, 0, 95, 0, 0, 1),       # single-row GEMM, ragged N, fp32 out
+    (700, 1, 1, 512, 1, 0, 2048, 0, 0, 1),   # GEMM, many n-tiles
+    (1, 40, 40, 64, 3, 1, 320, 0, 1, 0),     # 3 n-tiles with a partial one
+]
+
+
+def _ref(x, w, scale, bias, pad, pool, relu):
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, padding=pad)
+    y = y * scale[None, :, None, None] + bias[None, :, None, None]
+    if relu:
+        y = F.relu(y)
+    if pool == 1:
+        y = F.max_pool2d(y, 2, 2)
+    elif pool == 2:
+        y = F.max_pool2d(y, (2, 1), (2, 1))
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from marie_icr_amd._lib import Context
+
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_matches_torch(ctx, case, prec):
+    from marie_icr_amd._lib import PREC_F16, PREC_F32, ConvDesc
+
+    B, H, W, Cin, K, pad, N, pool, relu, out_f32 = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.rand((B, H, W, Cin), generator=g) * 2 - 1
+    w = (torch.rand((N, K, K, Cin), generator=g) * 2 - 1) * (3.0 / (K * K * Cin)) ** 0.5
+    scale = torch.rand((N,), generator=g) + 0.5
+    bias = torch.rand((N,), generator=g) - 0.5
+    tdt = torch.float16 if prec == "f16" else torch.float32
+    xq, wq = x.to(tdt), w.to(tdt)
+    ref = _ref(xq.float(), wq.float(), scale, bias, pad, pool, relu)   # same rounded operands, fp32 math
+    dx, dw = xq.cuda(), wq.cuda()
+    ds, db = scale.cuda(), bias.cuda()
+    odt = torch.float32 if out_f32 else tdt
+    out = torch.full(ref.shape, float("nan"), dtype=odt, device="cuda")
+    d = ConvDesc(B, H, W, Cin, K, K, pad, N, pool, relu, out_f32)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.conv2d_nhwc(PREC_F16 if prec == "f16" else PREC_F32, d, dx.data_ptr(), dw.data_ptr(), ds.data_ptr(),
+                    db.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert not torch.isnan(got).any(), "unwritten output elements"
+    tol = 2e-5 if (prec == "f32") else (2e-5 if out_f32 else 2e-3)   # f16 output rounding dominates
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), (case, prec, err)
+
+
+def test_conv_rejects_bad_cin(ctx):
+    from marie_icr_amd._lib import MarieHipError, PREC_F16, ConvDesc
+
+    x = torch.zeros((1, 4, 4, 48), dtype=torch.float16, device="cuda")
+    w = torch.zeros((64, 3, 3, 48), dtype=torch.float16, device="cuda")
+    o = torch.zeros((1, 4, 4, 64), dtype=torch.float16, device="cuda")
+    with pytest.raises(MarieHipError):
+        ctx.conv2d_nhwc(PREC_F16, ConvDesc(1, 4, 4, 48, 3, 3, 1, 64, 0, 0, 0), x.data_ptr(), w.data_ptr(), 0, 0,
+                        o.data_ptr())
