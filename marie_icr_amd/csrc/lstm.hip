@@ -201,14 +201,6 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_resident_f16(const float* __r
 template <typename T>
 struct Lt;
 template <>
-struct Lt<_Float16> {
-  static constexpr int E = 8;
-  typedef half8 chunk_t;
-  static __device__ __forceinline__ void mma(const chunk_t& a, const chunk_t& b, float4v& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-  }
-};
-template <>
 struct Lt<float> {
   static constexpr int E = 4;
   typedef float4v chunk_t;
