@@ -106,3 +106,91 @@ def make_crnn_input(seed: int, n: int, h: int = 32, w: int = 256) -> np.ndarray:
     up = np.repeat(np.repeat(base, 4, axis=1), 4, axis=2)[:, :h, :w]
     noise = rng.integers(-24, 25, size=(n, h, w)).astype(np.float32)
     return np.clip(up + noise, 0, 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------- #
+# CRAFT text detector
+# --------------------------------------------------------------------------- #
+# (state_dict prefix, Cout, Cin, k, BatchNorm prefix or None) in forward order.  Checkpoint keys are
+# the reference's CRAFT.state_dict() (marie/models/craft/craft.py:31-58,
+# marie/models/craft/basenet/vgg16_bn.py:23-49: slices index into torchvision's vgg16_bn().features).
+CRAFT_CONVS = (
+    ("basenet.slice1.0", 64, 3, 3, "basenet.slice1.1"),
+    ("basenet.slice1.3", 64, 64, 3, "basenet.slice1.4"),
+    ("basenet.slice1.7", 128, 64, 3, "basenet.slice1.8"),
+    ("basenet.slice1.10", 128, 128, 3, "basenet.slice1.11"),
+    ("basenet.slice2.14", 256, 128, 3, "basenet.slice2.15"),
+    ("basenet.slice2.17", 256, 256, 3, "basenet.slice2.18"),
+    ("basenet.slice3.20", 256, 256, 3, "basenet.slice3.21"),
+    ("basenet.slice3.24", 512, 256, 3, "basenet.slice3.25"),
+    ("basenet.slice3.27", 512, 512, 3, "basenet.slice3.28"),
+    ("basenet.slice4.30", 512, 512, 3, "basenet.slice4.31"),
+    ("basenet.slice4.34", 512, 512, 3, "basenet.slice4.35"),
+    ("basenet.slice4.37", 512, 512, 3, "basenet.slice4.38"),
+    ("basenet.slice5.1", 1024, 512, 3, None),     # dilation 6, padding 6
+    ("basenet.slice5.2", 1024, 1024, 1, None),
+    ("upconv1.conv.0", 512, 1536, 1, "upconv1.conv.1"),
+    ("upconv1.conv.3", 256, 512, 3, "upconv1.conv.4"),
+    ("upconv2.conv.0", 256, 768, 1, "upconv2.conv.1"),
+    ("upconv2.conv.3", 128, 256, 3, "upconv2.conv.4"),
+    ("upconv3.conv.0", 128, 384, 1, "upconv3.conv.1"),
+    ("upconv3.conv.3", 64, 128, 3, "upconv3.conv.4"),
+    ("upconv4.conv.0", 64, 192, 1, "upconv4.conv.1"),
+    ("upconv4.conv.3", 32, 64, 3, "upconv4.conv.4"),
+    ("conv_cls.0", 32, 32, 3, None),
+    ("conv_cls.2", 32, 32, 3, None),
+    ("conv_cls.4", 16, 32, 3, None),
+    ("conv_cls.6", 16, 16, 1, None),
+    ("conv_cls.8", 2, 16, 1, None),
+)
+
+
+def make_craft_state(seed: int = 0, score_gain: float = 4.0) -> Dict[str, np.ndarray]:
+    """Seeded CRAFT weights with O(1) activations (He-uniform convs, non-trivial BatchNorm statistics).
+    The last layer is scaled so the two score maps straddle the reference thresholds (0.3 / 0.45 / 0.7),
+    which makes the post-processing do real work on random weights."""
+    rng = np.random.Generator(np.random.PCG64(seed + 104729))
+    st: Dict[str, np.ndarray] = {}
+
+    def uni(shape, bound):
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    for name, co, ci, k, bn in CRAFT_CONVS:
+        fan_in = ci * k * k
+        gain = score_gain if name == "conv_cls.8" else 1.0
+        st[name + ".weight"] = uni((co, ci, k, k), gain * np.sqrt(6.0 / fan_in))
+        st[name + ".bias"] = uni((co,), 0.1)
+        if bn:
+            st[bn + ".weight"] = rng.uniform(0.6, 1.4, size=(co,)).astype(np.float32)
+            st[bn + ".bias"] = uni((co,), 0.2)
+            st[bn + ".running_mean"] = uni((co,), 0.3)
+            st[bn + ".running_var"] = rng.uniform(0.5, 1.5, size=(co,)).astype(np.float32)
+            st[bn + ".num_batches_tracked"] = np.asarray(0, dtype=np.int64)
+    return st
+
+
+def make_page_bgr(seed: int, h: int, w: int, n_lines: int = 0) -> np.ndarray:
+    """Seeded synthetic page, uint8 HxWx3 (BGR like OpenCV): white paper, dark word-like blocks laid out
+    on text lines, mild noise.  Deterministic across platforms (PCG64 + integer arithmetic only)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 15485863))
+    img = np.full((h, w, 3), 255, np.uint8)
+    if n_lines <= 0:
+        n_lines = max(1, h // 80)
+    pitch = h // (n_lines + 1)
+    gh = max(6, int(pitch * 0.5))
+    for li in range(n_lines):
+        y0 = pitch * (li + 1) - gh // 2
+        x = w // 16
+        while x < w - w // 16:
+            ww = int(rng.integers(gh, 4 * gh + 1))
+            if x + ww >= w - w // 16:
+                break
+            shade = int(rng.integers(0, 90))
+            # a "word": a block with a few vertical gaps so that it has stroke-like structure
+            block = np.full((gh, ww, 3), shade, np.uint8)
+            for gx in range(gh // 2, ww, max(3, gh // 2)):
+                block[:, gx:gx + 1] = 255
+            img[y0:y0 + gh, x:x + ww] = block
+            x += ww + int(rng.integers(gh // 2, gh + 1))
+    noise = rng.integers(-6, 7, size=img.shape).astype(np.int16)
+    return np.clip(img.astype(np.int16) + noise, 0, 255).astype(np.uint8)

@@ -70,9 +70,68 @@ def _run(m, conv, crops_u8):
             np.array([s.upper() for s in strs]), conf.numpy())
 
 
+def _install_torchvision_standin():
+    """torchvision is not installed here and not vendored by the reference.  The reference only needs
+    ``torchvision.models.vgg16_bn(pretrained).features`` (marie/models/craft/basenet/vgg16_bn.py:27); this is
+    that published layer list (VGG cfg "D" with BatchNorm: conv3x3 p1 / BatchNorm2d / ReLU(inplace=True), "M" =
+    MaxPool2d(2, 2)) — a restatement of the absent third-party module, recorded as such in DESIGN.md."""
+    import types
+
+    import torch.nn as nn
+
+    cfg_d = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+
+    class _VGG(nn.Module):
+        def __init__(self):
+            super().__init__()
+            layers, cin = [], 3
+            for v in cfg_d:
+                if v == "M":
+                    layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                else:
+                    layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+                    cin = v
+            self.features = nn.Sequential(*layers)
+
+    tv = types.ModuleType("torchvision")
+    models = types.ModuleType("torchvision.models")
+    models.vgg16_bn = lambda pretrained=False, **kw: _VGG()
+    tv.models = models
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = models
+
+
+def gen_craft(out_dir):
+    """CRAFT network goldens: the reference's unmodified CRAFT class on seeded weights."""
+    from marie_icr_amd.weights import make_craft_state, make_page_bgr
+    from oracle.craft_ref import craft_preprocess
+
+    _install_torchvision_standin()
+    sys.path.insert(0, "/root/reference/marie/models/craft")
+    from craft import CRAFT  # reference: marie/models/craft/craft.py:31
+
+    for tag, seed, (h, w) in (("a", 0, (130, 170)), ("b", 1, (210, 160))):
+        st = make_craft_state(seed)
+        net = CRAFT(pretrained=False).eval()
+        missing = net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}, strict=True)
+        page = make_page_bgr(seed, h, w)
+        x, ratio, (th, tw) = craft_preprocess(page, canvas_size=w, mag_ratio=1.0)
+        with torch.no_grad():
+            y, feature = net(torch.from_numpy(x))
+        np.savez_compressed(
+            os.path.join(out_dir, f"craft_net_{tag}.npz"),
+            weight_seed=seed, weight_sha256=state_checksum(st), page_seed=seed, page_hw=np.array([h, w]),
+            x_shape=np.array(x.shape), y=y.numpy(), feature_sub=feature.numpy()[:, ::4, ::3, ::3])
+        print("craft", tag, tuple(x.shape), "->", tuple(y.shape), "text range", float(y[..., 0].min()),
+              float(y[..., 0].max()), "link range", float(y[..., 1].min()), float(y[..., 1].max()), missing)
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if "--craft-only" in sys.argv:
+        gen_craft(out_dir)
+        return
 
     # (1) seeded "scaled" weights, 8 crops 32x256 (BASELINE config-2 shape)
     # (2) same weights, ragged width 32x100 (the production imgW) — exercises odd W
@@ -100,6 +159,7 @@ def main():
         weight_seed=0, input_seed=11, weight_sha256=state_checksum(ours),
         crops_u8=crops, logits=logits, argmax=idx, strings=strs, confidence=conf)
     print("default", logits.shape, "max|logit|", np.abs(logits).max(), strs[:2], conf[:2])
+    gen_craft(out_dir)
 
 
 if __name__ == "__main__":
