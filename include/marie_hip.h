@@ -74,9 +74,14 @@ typedef struct mhip_conv_desc {
   int32_t KH, KW, pad;  /* filter [N][KH][KW][Cin] */
   int32_t N;            /* output channels */
   int32_t pool, relu, out_f32;
+  int32_t dil;          /* filter dilation, 0/1 = dense */
+  int32_t Cin1;         /* with in2_dev: channels [0,Cin1) come from in_dev, [Cin1,Cin) from in2_dev */
 } mhip_conv_desc;
+/* in2_dev (may be NULL) is the second tensor of a channel-concatenated input, torch.cat([a, b], dim=1) followed
+ * by a 1x1 conv (marie/models/craft/craft.py:63-64,67-69): the concatenation is never materialised.      */
 int mhip_conv2d_nhwc(mhip_ctx* ctx, int precision, const mhip_conv_desc* d, const void* in_dev,
-                     const void* w_dev, const float* scale_dev, const float* bias_dev, void* out_dev);
+                     const void* in2_dev, const void* w_dev, const float* scale_dev, const float* bias_dev,
+                     void* out_dev);
 
 /* ---- CRNN-family recognizer: None-VGG-BiLSTM-CTC ---------------------------------- */
 /* replaces: Model(opt) construction, marie/models/icr/model.py:27-68 (Trans=None, Feat=VGG,
@@ -125,6 +130,38 @@ size_t mhip_crnn_workspace_bytes(mhip_crnn* m, int n, int w);
 /* Algorithmic FLOPs (2*MAC) of one forward of n lines of width w, per kernel id — what
  * bench.py divides by the measured kernel time for the roofline line.                    */
 double mhip_crnn_kernel_flops(mhip_crnn* m, int kernel_id, int n, int w);
+
+/* ---- CRAFT text detector -------------------------------------------------------------------- */
+typedef struct mhip_craft mhip_craft;
+/* replaces: CRAFT() + load_state_dict(copyStateDict(torch.load(...))), marie/boxes/craft_box_processor.py:260-285.
+ * Keys are CRAFT.state_dict() names ("basenet.slice1.0.weight", "upconv1.conv.0.weight", "conv_cls.8.bias", ...;
+ * a "module." prefix is ignored).                                                                           */
+int mhip_craft_create(mhip_ctx* ctx, int precision, mhip_craft** out);
+int mhip_craft_destroy(mhip_craft* m);
+int mhip_craft_set_tensor(mhip_craft* m, const char* key, const float* data_host, const int64_t* shape, int ndim);
+int mhip_craft_finalize(mhip_craft* m);
+int mhip_craft_alloc_arena(mhip_craft* m);
+int mhip_craft_arena(mhip_craft* m, void** arena_dev, size_t* bytes);
+/* replaces: resize_aspect_ratio's size arithmetic, marie/models/craft/imgproc.py:45-71.
+ * (h, w) page -> ratio, resized (th, tw), /32 canvas (H32, W32); the score maps are H32/2 x W32/2.          */
+int mhip_craft_geometry(int h, int w, int canvas_size, double mag_ratio, double* ratio, int* th, int* tw,
+                        int* H32, int* W32);
+size_t mhip_craft_workspace_bytes(mhip_craft* m, int h, int w, int canvas_size, double mag_ratio);
+/* replaces: get_prediction's resize + normalizeMeanVariance + net(x), craft_box_processor.py:94-110.
+ * page_dev uint8 [h][w][3] (channel order as given, the reference feeds BGR) -> scores_dev fp32 [H32/2][W32/2][2]
+ * (channel 0 = text/region score, 1 = link/affinity score).                                                  */
+int mhip_craft_forward(mhip_craft* m, const uint8_t* page_dev, int h, int w, int canvas_size, double mag_ratio,
+                       float* scores_dev);
+/* replaces: get_prediction incl. getDetBoxes_core (marie/models/craft/craft_utils.py:25-98): forward, threshold,
+ * 4-connected components with statistics (GPU), then per component dilate + minAreaRect + diamond fix + clockwise
+ * order.  boxes_host gets n_boxes x 4 corners x (x, y) fp32 in SCORE-MAP coordinates, in OpenCV label order
+ * (adjustResultCoordinates is the caller's, as in the reference).  scores_host (may be NULL) receives the maps. */
+int mhip_craft_detect(mhip_craft* m, const uint8_t* page_dev, int h, int w, int canvas_size, double mag_ratio,
+                      float text_threshold, float link_threshold, float low_text, float* boxes_host,
+                      int max_boxes, int* n_boxes, float* scores_host, double* ratio_out);
+int mhip_craft_detect_host(mhip_craft* m, const uint8_t* page_host, int h, int w, int canvas_size,
+                           double mag_ratio, float text_threshold, float link_threshold, float low_text,
+                           float* boxes_host, int max_boxes, int* n_boxes, float* scores_host, double* ratio_out);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MARIE_HIP_LIB selects another build of the same library (kernel A/B experiments); never a fallback
@@ -31,7 +32,21 @@ _SIGNATURES = (
     ("mhip_profile_read", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("mhip_kernel_count", _i, []),
     ("mhip_kernel_name", C.c_char_p, [_i]),
-    ("mhip_conv2d_nhwc", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_conv2d_nhwc", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_craft_create", _i, [_vp, _i, C.POINTER(_vp)]),
+    ("mhip_craft_destroy", _i, [_vp]),
+    ("mhip_craft_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
+    ("mhip_craft_finalize", _i, [_vp]),
+    ("mhip_craft_alloc_arena", _i, [_vp]),
+    ("mhip_craft_arena", _i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    ("mhip_craft_geometry", _i, [_i, _i, _i, C.c_double, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_i),
+                                 C.POINTER(_i), C.POINTER(_i)]),
+    ("mhip_craft_workspace_bytes", _sz, [_vp, _i, _i, _i, C.c_double]),
+    ("mhip_craft_forward", _i, [_vp, _vp, _i, _i, _i, C.c_double, _vp]),
+    ("mhip_craft_detect", _i, [_vp, _vp, _i, _i, _i, C.c_double, C.c_float, C.c_float, C.c_float, _vp, _i,
+                               C.POINTER(_i), _vp, C.POINTER(C.c_double)]),
+    ("mhip_craft_detect_host", _i, [_vp, _vp, _i, _i, _i, C.c_double, C.c_float, C.c_float, C.c_float, _vp, _i,
+                                    C.POINTER(_i), _vp, C.POINTER(C.c_double)]),
     ("mhip_crnn_create", _i, [_vp, _i, _i, C.POINTER(_vp)]),
     ("mhip_crnn_destroy", _i, [_vp]),
     ("mhip_crnn_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
@@ -50,7 +65,8 @@ EXPORTED_SYMBOLS = tuple(s[0] for s in _SIGNATURES)
 
 class ConvDesc(C.Structure):
     """mirror of ``mhip_conv_desc`` (include/marie_hip.h)"""
-    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "KH", "KW", "pad", "N", "pool", "relu", "out_f32")]
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "KH", "KW", "pad", "N", "pool", "relu", "out_f32",
+                                         "dil", "Cin1")]
 
 
 POOL_NONE, POOL_2x2, POOL_2x1 = 0, 1, 2
@@ -99,6 +115,10 @@ class Context:
         self.h = h
         self.lib = lib
         self.device_id = int(device_id)
+        self._children = weakref.WeakSet()   # models created on this context; closed before the context is
+
+    def adopt(self, child):
+        self._children.add(child)
 
     def set_stream(self, stream_handle: int | None):
         check(self.h, self.lib.mhip_set_stream(self.h, C.c_void_p(stream_handle or 0)), "mhip_set_stream")
@@ -118,10 +138,10 @@ class Context:
               "mhip_memcpy_dev")
 
     def conv2d_nhwc(self, precision: int, desc: "ConvDesc", in_ptr: int, w_ptr: int, scale_ptr: int, bias_ptr: int,
-                    out_ptr: int):
+                    out_ptr: int, in2_ptr: int = 0):
         """Enqueue one NHWC conv/GEMM on the ctx stream; pointers are HBM addresses."""
         check(self.h, self.lib.mhip_conv2d_nhwc(self.h, int(precision), C.byref(desc), C.c_void_p(in_ptr),
-                                                C.c_void_p(w_ptr), C.c_void_p(scale_ptr or 0),
+                                                C.c_void_p(in2_ptr or 0), C.c_void_p(w_ptr), C.c_void_p(scale_ptr or 0),
                                                 C.c_void_p(bias_ptr or 0), C.c_void_p(out_ptr)),
               "mhip_conv2d_nhwc")
 
@@ -142,6 +162,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
+            for child in list(getattr(self, "_children", ())):
+                child.close()
             self.lib.mhip_destroy(self.h)
             self.h = C.c_void_p()
 

@@ -36,6 +36,7 @@ class CrnnModel:
         h = C.c_void_p()
         check(ctx.h, self.lib.mhip_crnn_create(ctx.h, self.precision, self.num_class, C.byref(h)), "mhip_crnn_create")
         self.h = h
+        ctx.adopt(self)
         if state is not None:
             self.load_state(state)
 

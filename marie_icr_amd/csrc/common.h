@@ -16,7 +16,9 @@ enum MhipKernelId {
   MHIP_K_CONV_IGEMM = 1,  // NHWC implicit-GEMM conv / GEMM on MFMA, fused scale/bias/ReLU/pool
   MHIP_K_LSTM_REC = 2,    // BiLSTM recurrence (persistent over T, batch-sliced)
   MHIP_K_CTC_DECODE = 3,  // wave-shuffle argmax + softmax-max + collapse
-  MHIP_K_COUNT = 4
+  MHIP_K_IMAGE_OPS = 4,   // resize / max-pool / bilinear up-sample (HBM-bound, 16 B per lane)
+  MHIP_K_CCL = 5,         // score-map binarise + connected components + per-component statistics
+  MHIP_K_COUNT = 6
 };
 
 struct ProfSlot {
@@ -78,6 +80,9 @@ struct ConvDesc {
   int pool = POOL_NONE;
   int relu = 0;
   int out_f32 = 0;
+  int dil = 1;                  // filter dilation
+  const void* in2 = nullptr;    // optional second input: channels [Cin1, Cin) of a 1x1 conv over cat(in, in2)
+  int Cin1 = 0;
 };
 // precision: MHIP_PREC_F16 / MHIP_PREC_F32.  Returns 0 or negative error.
 int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d);
@@ -101,3 +106,31 @@ void mhip_lstm_pack_whh(int precision, const float* whh_fwd, const float* whh_bw
 // greedy CTC decode
 int mhip_launch_ctc_decode(mhip_ctx* ctx, const float* logits, int n, int T, int C, int32_t* argmax,
                            int32_t* tokens, int32_t* lengths, float* conf);
+
+// ------------------------------------------------------------------ detector image ops (image_ops.hip)
+void mhip_resize_linear_tables(int src, int dst, std::vector<int>& ofs, std::vector<short>& coef);
+int mhip_launch_resize_linear_u8(mhip_ctx* ctx, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw,
+                                 const int* xofs, const short* xa, const int* yofs, const short* yb);
+int mhip_launch_conv_rgb_first(mhip_ctx* ctx, int precision, const uint8_t* img, int th, int tw, int H, int W,
+                               const float* w27x64, const float* scale, const float* bias, void* out);
+int mhip_launch_maxpool(mhip_ctx* ctx, int precision, int k, const void* in, void* out, int B, int H, int W, int C);
+int mhip_launch_upsample_bilinear(mhip_ctx* ctx, int precision, const void* in, void* out, int B, int Hi, int Wi,
+                                  int C, int Ho, int Wo);
+
+// ------------------------------------------------------------------ score-map post-processing (ccl.hip)
+// scores fp32 [H][W][2] (text, link) -> flags u8 (bit0 text > low_text, bit1 link > link_thr), labels int32
+// (0 = background, components numbered in raster order of their first pixel), n_labels (incl. background) and
+// per-component stats int32 [n][6] = {left, top, right, bottom, area, max text score as ordered int bits}.
+struct CclBuffers {
+  uint8_t* flags;   // [H*W]
+  int* parent;      // [H*W]  union-find forest, then root index per pixel
+  int* labels;      // [H*W]
+  int* blocksum;    // [ceil(H*W/2048) + 1]
+  int* stats;       // [max_labels][6]
+  int* n_labels;    // [1]
+};
+size_t mhip_ccl_workspace_bytes(int H, int W);
+void mhip_ccl_carve(char* base, int H, int W, CclBuffers* out);
+int mhip_launch_ccl(mhip_ctx* ctx, const float* scores, int H, int W, float low_text, float link_thr,
+                    const CclBuffers& b);
+float mhip_ordered_bits_to_float(int bits);

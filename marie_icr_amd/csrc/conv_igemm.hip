@@ -76,6 +76,9 @@ struct IgemmArgs {
   int cpt;       // slices per tap
   int relu, out_f32;
   int mtiles, ntiles;
+  int dil;             // filter dilation (1 = dense)
+  const char* in2;     // second input of a channel-concatenated 1x1 conv (DUAL kernels only)
+  int Cin1;            // channels taken from `in`; the remaining Cin - Cin1 come from `in2`
 };
 
 template <typename T>
@@ -136,7 +139,7 @@ __device__ __forceinline__ void lds_put(char* base, int pitch, int row, int col,
   *(OT*)(base + row * pitch + col * (int)sizeof(OT)) = (OT)v;
 }
 
-template <typename T, int POOL, int BN_>
+template <typename T, int POOL, int BN_, bool DUAL>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Cfg<BN_> C;
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     a_y[q] = y;
     a_x[q] = x;
     size_t pix = ((size_t)b * p.H + (y - p.pad)) * p.W + (x - p.pad);  // tap (0,0) position (guarded)
-    a_src[q] = p.in + (pix * p.Cin + (size_t)lchunk * E) * sizeof(T);
+    if (DUAL) a_src[q] = (const char*)pix;  // 1x1 concat conv: keep the pixel index, pick the tensor per slice
+    else a_src[q] = p.in + (pix * p.Cin + (size_t)lchunk * E) * sizeof(T);
   }
 #pragma unroll
   for (int q = 0; q < C::WCHUNKS; ++q) {
@@ -182,16 +186,24 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 
   auto stage = [&](int it, int slot) {
     int tap = it / p.cpt, cc = it - tap * p.cpt;
-    int dy = tap / p.KW, dx = tap - dy * p.KW;
+    int dy = (tap / p.KW) * p.dil, dx = (tap - (tap / p.KW) * p.KW) * p.dil;
     size_t a_off = (((size_t)dy * p.W + dx) * p.Cin + (size_t)cc * BKE) * sizeof(T);
     size_t w_off = (size_t)it * BKE * sizeof(T);
     char* la = smem + slot * C::STAGE_BYTES + wave * 8 * ROWB;
     char* lb = la + A_BYTES;
+    // DUAL (KH = KW = 1, pad = 0): channel slice cc comes from `in` or from `in2`
+    const int c0 = cc * BKE + lchunk * E;
+    const bool first = c0 < p.Cin1;
+    const char* dbase = first ? p.in : p.in2;
+    const size_t dstride = (size_t)(first ? p.Cin1 : p.Cin - p.Cin1) * sizeof(T);
+    const size_t dcol = (size_t)(first ? c0 : c0 - p.Cin1) * sizeof(T);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       int yy = a_y[q] + dy - p.pad, xx = a_x[q] + dx - p.pad;
       bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      const char* src = ok ? a_src[q] + a_off : p.zeros;
+      const char* src;
+      if (DUAL) src = ok ? dbase + (size_t)a_src[q] * dstride + dcol : p.zeros;
+      else src = ok ? a_src[q] + a_off : p.zeros;
       glds16(src, la + q * 64 * ROWB);
     }
 #pragma unroll
@@ -347,27 +359,32 @@ int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
   const size_t lds = Cfg<BN_>::LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, POOL_NONE, BN_>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, POOL_2x2, BN_>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, POOL_2x1, BN_>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define SETATTR(...) (void)hipFuncSetAttribute((const void*)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    SETATTR(conv_igemm_kernel<T, POOL_NONE, BN_, false>);
+    SETATTR(conv_igemm_kernel<T, POOL_2x2, BN_, false>);
+    SETATTR(conv_igemm_kernel<T, POOL_2x1, BN_, false>);
+    SETATTR(conv_igemm_kernel<T, POOL_NONE, BN_, true>);
+#undef SETATTR
     attr_set = true;
   }
-  switch (pool) {
-    case POOL_NONE:
-      PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
-                  hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, BN_>), grid, block, lds, ctx->stream, a));
-      break;
-    case POOL_2x2:
-      PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
-                  hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x2, BN_>), grid, block, lds, ctx->stream, a));
-      break;
-    default:
-      PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
-                  hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x1, BN_>), grid, block, lds, ctx->stream, a));
-      break;
+  if (a.in2) {
+    PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+                hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, BN_, true>), grid, block, lds, ctx->stream, a));
+  } else {
+    switch (pool) {
+      case POOL_NONE:
+        PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+                    hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, BN_, false>), grid, block, lds, ctx->stream, a));
+        break;
+      case POOL_2x2:
+        PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+                    hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x2, BN_, false>), grid, block, lds, ctx->stream, a));
+        break;
+      default:
+        PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+                    hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x1, BN_, false>), grid, block, lds, ctx->stream, a));
+        break;
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "conv_igemm launch: %s", hipGetErrorString(e));
@@ -377,7 +394,8 @@ int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
 }  // namespace
 
 double mhip_conv_flops(const ConvDesc& d) {
-  int Ho = d.H + 2 * d.pad - d.KH + 1, Wo = d.W + 2 * d.pad - d.KW + 1;
+  const int dil = d.dil > 0 ? d.dil : 1;
+  int Ho = d.H + 2 * d.pad - dil * (d.KH - 1), Wo = d.W + 2 * d.pad - dil * (d.KW - 1);
   return 2.0 * d.B * Ho * Wo * (double)d.N * d.KH * d.KW * d.Cin;
 }
 
@@ -396,8 +414,17 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.zeros = (const char*)ctx->zeros;
   a.B = d.B; a.H = d.H; a.W = d.W; a.Cin = d.Cin;
   a.KH = d.KH; a.KW = d.KW; a.pad = d.pad;
-  a.Ho = d.H + 2 * d.pad - d.KH + 1;
-  a.Wo = d.W + 2 * d.pad - d.KW + 1;
+  a.dil = d.dil > 0 ? d.dil : 1;
+  a.Ho = d.H + 2 * d.pad - a.dil * (d.KH - 1);
+  a.Wo = d.W + 2 * d.pad - a.dil * (d.KW - 1);
+  a.in2 = (const char*)d.in2;
+  a.Cin1 = d.in2 ? d.Cin1 : d.Cin;
+  if (d.in2) {
+    if (d.KH != 1 || d.KW != 1 || d.pad != 0 || d.pool != POOL_NONE)
+      return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: a concatenated input needs a 1x1, unpadded, unpooled conv");
+    if (d.Cin1 <= 0 || d.Cin1 >= d.Cin || d.Cin1 % bke != 0)
+      return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: Cin1=%d must split Cin=%d on a multiple of %d", d.Cin1, d.Cin, bke);
+  }
   if (a.Ho <= 0 || a.Wo <= 0) return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: empty output %dx%d", a.Ho, a.Wo);
   a.Hp = a.Ho; a.Wp = a.Wo;
   long long M;

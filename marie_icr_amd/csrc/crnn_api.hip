@@ -21,7 +21,8 @@ int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "lstm_rec", "ctc_decode"};
+static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "lstm_rec",
+                                                 "ctc_decode", "image_ops",  "ccl"};
 
 extern "C" int mhip_kernel_count(void) { return MHIP_K_COUNT; }
 extern "C" const char* mhip_kernel_name(int k) { return (k >= 0 && k < MHIP_K_COUNT) ? kKernelNames[k] : ""; }
@@ -168,7 +169,7 @@ extern "C" int mhip_profile_read(mhip_ctx* ctx, int kid, double* total_ms, int64
 
 // ======================================================================= conv primitive
 extern "C" int mhip_conv2d_nhwc(mhip_ctx* ctx, int precision, const mhip_conv_desc* d, const void* in,
-                                const void* w, const float* scale, const float* bias, void* out) {
+                                const void* in2, const void* w, const float* scale, const float* bias, void* out) {
   if (!ctx || !d) return MHIP_EINVAL;
   if (precision != MHIP_PREC_F16 && precision != MHIP_PREC_F32)
     return mhip_fail(ctx, MHIP_EINVAL, "unknown precision %d", precision);
@@ -181,6 +182,8 @@ extern "C" int mhip_conv2d_nhwc(mhip_ctx* ctx, int precision, const mhip_conv_de
   c.B = d->B; c.H = d->H; c.W = d->W; c.Cin = d->Cin;
   c.KH = d->KH; c.KW = d->KW; c.pad = d->pad;
   c.N = d->N; c.pool = d->pool; c.relu = d->relu; c.out_f32 = d->out_f32;
+  c.dil = d->dil > 0 ? d->dil : 1;
+  c.in2 = in2; c.Cin1 = d->Cin1;
   return mhip_launch_conv_igemm(ctx, precision, c);
 }
 

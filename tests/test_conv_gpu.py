@@ -60,7 +60,7 @@ def test_conv_matches_torch(ctx, case, prec):
     ds, db = scale.cuda(), bias.cuda()
     odt = torch.float32 if out_f32 else tdt
     out = torch.full(ref.shape, float("nan"), dtype=odt, device="cuda")
-    d = ConvDesc(B, H, W, Cin, K, K, pad, N, pool, relu, out_f32)
+    d = ConvDesc(B, H, W, Cin, K, K, pad, N, pool, relu, out_f32, 1, 0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.conv2d_nhwc(PREC_F16 if prec == "f16" else PREC_F32, d, dx.data_ptr(), dw.data_ptr(), ds.data_ptr(),
                     db.data_ptr(), out.data_ptr())
@@ -79,5 +79,5 @@ def test_conv_rejects_bad_cin(ctx):
     w = torch.zeros((64, 3, 3, 48), dtype=torch.float16, device="cuda")
     o = torch.zeros((1, 4, 4, 64), dtype=torch.float16, device="cuda")
     with pytest.raises(MarieHipError):
-        ctx.conv2d_nhwc(PREC_F16, ConvDesc(1, 4, 4, 48, 3, 3, 1, 64, 0, 0, 0), x.data_ptr(), w.data_ptr(), 0, 0,
+        ctx.conv2d_nhwc(PREC_F16, ConvDesc(1, 4, 4, 48, 3, 3, 1, 64, 0, 0, 0, 1, 0), x.data_ptr(), w.data_ptr(), 0, 0,
                         o.data_ptr())

@@ -51,7 +51,7 @@ def main():
         Ho, Wo = H + 2 * pad - K + 1, W + 2 * pad - K + 1
         Hp, Wp = (Ho // 2, Wo // 2) if pool == 1 else ((Ho // 2, Wo) if pool == 2 else (Ho, Wo))
         out = torch.empty((B, Hp, Wp, N), dtype=torch.float32 if of32 else tdt, device="cuda")
-        d = ConvDesc(B, H, W, Cin, K, K, pad, N, pool, relu, of32)
+        d = ConvDesc(B, H, W, Cin, K, K, pad, N, pool, relu, of32, 1, 0)
         flops = 2.0 * B * Ho * Wo * N * K * K * Cin
         bufs.append((name, d, x, w, bias, out, flops))
     times = {b[0]: [] for b in bufs}
