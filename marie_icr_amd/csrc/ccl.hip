@@ -19,14 +19,41 @@ __device__ __forceinline__ int float_to_ordered(float f) {
   return b >= 0 ? b : b ^ 0x7fffffff;  // monotone: larger float -> larger int
 }
 
-__global__ __launch_bounds__(256) void ccl_binarise_kernel(const float* __restrict__ scores, int n, float low_text,
-                                                           float link_thr, uint8_t* __restrict__ flags,
-                                                           int* __restrict__ parent) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float2 s = ((const float2*)scores)[i];
-    const uint8_t f = (s.x > low_text ? 1 : 0) | (s.y > link_thr ? 2 : 0);   // cv2.threshold: strictly greater
-    flags[i] = f;
-    parent[i] = f ? i : -1;
+// One block per score-map row: binarise, and point every foreground pixel at the first pixel of its horizontal
+// run (prefix-max of "last background x" over the row).  Runs, not pixels, are then the union-find elements, so a
+// page-sized blob costs one union per row instead of a million contended atomics.
+__global__ __launch_bounds__(256) void ccl_rows_kernel(const float* __restrict__ scores, int H, int W,
+                                                       float low_text, float link_thr, uint8_t* __restrict__ flags,
+                                                       int* __restrict__ parent) {
+  __shared__ int wmax[4];
+  __shared__ int carry_s;
+  const int y = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = -1;
+  __syncthreads();
+  for (int x0 = 0; x0 < W; x0 += 256) {
+    const int x = x0 + threadIdx.x;
+    uint8_t f = 0;
+    if (x < W) {
+      const float2 s = ((const float2*)scores)[(size_t)y * W + x];
+      f = (s.x > low_text ? 1 : 0) | (s.y > link_thr ? 2 : 0);   // cv2.threshold: strictly greater
+      flags[(size_t)y * W + x] = f;
+    }
+    int v = (x < W && f == 0) ? x : -1;          // last background position so far
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {     // inclusive max-scan inside the wave
+      int o = __shfl_up(v, off);
+      if (lane >= off) v = max(v, o);
+    }
+    if (lane == 63) wmax[wave] = v;
+    __syncthreads();
+    int pre = carry_s;
+    for (int q = 0; q < wave; ++q) pre = max(pre, wmax[q]);
+    v = max(v, pre);
+    if (x < W) parent[(size_t)y * W + x] = f ? y * W + (v + 1) : -1;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = v;         // v of the last thread = max over the whole segment
+    __syncthreads();
   }
 }
 
@@ -55,19 +82,39 @@ __device__ __forceinline__ void unite(int* L, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void ccl_merge_kernel(int* __restrict__ parent, int H, int W) {
+// one union per pair of vertically touching runs: at the first column of every contact segment
+__global__ __launch_bounds__(256) void ccl_merge_kernel(int* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                                        int H, int W) {
   const int n = H * W;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (parent[i] < 0) continue;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x + W; i < n; i += gridDim.x * blockDim.x) {
+    if (!flags[i] || !flags[i - W]) continue;
     const int x = i % W;
-    if (x > 0 && parent[i - 1] >= 0) unite(parent, i, i - 1);
-    if (i >= W && parent[i - W] >= 0) unite(parent, i, i - W);
+    if (x > 0 && flags[i - 1] && flags[i - W - 1]) continue;   // same contact segment as the pixel on the left
+    unite(parent, parent[i], parent[i - W]);
   }
 }
 
-__global__ __launch_bounds__(256) void ccl_flatten_kernel(int* __restrict__ parent, int n) {
+// compress the forest at the run heads (path to the root can be long for a tall blob) ...
+__global__ __launch_bounds__(256) void ccl_compress_heads_kernel(int* __restrict__ parent,
+                                                                 const uint8_t* __restrict__ flags, int H, int W) {
+  const int n = H * W;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (parent[i] >= 0) parent[i] = find_root(parent, i);   // roots only ever point to themselves: race-free
+    if (!flags[i]) continue;
+    const int x = i % W;
+    if (x > 0 && flags[i - 1]) continue;            // not a run head
+    const int r = find_root(parent, i);
+    if (r != i) parent[i] = r;                      // roots never change in this kernel: race-free
+  }
+}
+
+// ... then every other pixel takes its run head's (now final) root
+__global__ __launch_bounds__(256) void ccl_flatten_kernel(int* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                                          int H, int W) {
+  const int n = H * W;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (!flags[i]) continue;
+    const int x = i % W;
+    if (x > 0 && flags[i - 1]) parent[i] = parent[parent[i]];   // parent[i] is still the run head
   }
 }
 
@@ -138,27 +185,50 @@ __global__ __launch_bounds__(256) void ccl_rank_roots_kernel(const int* __restri
   }
 }
 
-// labels for non-root foreground pixels + statistics
+// labels for non-root foreground pixels + statistics.  A thread walks 8 consecutive pixels of a row and flushes
+// its partial (area, x-range, max score) only when the label changes: 8x fewer atomics inside large components.
 __global__ __launch_bounds__(256) void ccl_stats_kernel(const int* __restrict__ parent,
                                                         const float* __restrict__ scores, int H, int W,
                                                         int* __restrict__ labels, int* __restrict__ stats) {
-  const int n = H * W;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int r = parent[i];
-    if (r < 0) {
-      labels[i] = 0;
-      continue;
+  const int segs = (W + 7) / 8;
+  const long long total = (long long)H * segs;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)(t / segs), xs = (int)(t % segs) * 8, xe = min(xs + 8, W);
+    int cur = 0, area = 0, x0 = 0, x1 = 0, tmax = (int)0x80000000;
+    for (int x = xs; x <= xe; ++x) {
+      int k = 0;
+      if (x < xe) {
+        const size_t i = (size_t)y * W + x;
+        const int r = parent[i];
+        if (r >= 0) {
+          k = labels[r];                 // roots were labelled by the previous kernel
+          if ((size_t)r != i) labels[i] = k;
+        } else {
+          labels[i] = 0;
+        }
+      }
+      if (k != cur) {
+        if (cur) {
+          int* s = stats + (size_t)cur * 6;
+          atomicMin(&s[0], x0);
+          atomicMin(&s[1], y);
+          atomicMax(&s[2], x1);
+          atomicMax(&s[3], y);
+          atomicAdd(&s[4], area);
+          atomicMax(&s[5], tmax);
+        }
+        cur = k;
+        area = 0;
+        x0 = x;
+        tmax = (int)0x80000000;
+      }
+      if (k) {
+        ++area;
+        x1 = x;
+        tmax = max(tmax, float_to_ordered(scores[2 * ((size_t)y * W + x)]));
+      }
     }
-    const int k = labels[r];   // roots were labelled by the previous kernel
-    if (r != i) labels[i] = k;
-    const int x = i % W, y = i / W;
-    int* s = stats + (size_t)k * 6;
-    atomicMin(&s[0], x);
-    atomicMin(&s[1], y);
-    atomicMax(&s[2], x);
-    atomicMax(&s[3], y);
-    atomicAdd(&s[4], 1);
-    atomicMax(&s[5], float_to_ordered(scores[2 * (size_t)i]));
   }
 }
 
@@ -212,10 +282,11 @@ int mhip_launch_ccl(mhip_ctx* ctx, const float* scores, int H, int W, float low_
   const unsigned g = (unsigned)std::min<long long>(((long long)n + 255) / 256, 256 * 16);
   hipEvent_t e0 = nullptr;
   if (ctx->profiling) mhip_prof_begin(ctx, MHIP_K_CCL, &e0);
-  hipLaunchKernelGGL(ccl_binarise_kernel, dim3(g), dim3(256), 0, ctx->stream, scores, n, low_text, link_thr, b.flags,
+  hipLaunchKernelGGL(ccl_rows_kernel, dim3(H), dim3(256), 0, ctx->stream, scores, H, W, low_text, link_thr, b.flags,
                      b.parent);
-  hipLaunchKernelGGL(ccl_merge_kernel, dim3(g), dim3(256), 0, ctx->stream, b.parent, H, W);
-  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g), dim3(256), 0, ctx->stream, b.parent, n);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3(g), dim3(256), 0, ctx->stream, b.parent, b.flags, H, W);
+  hipLaunchKernelGGL(ccl_compress_heads_kernel, dim3(g), dim3(256), 0, ctx->stream, b.parent, b.flags, H, W);
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g), dim3(256), 0, ctx->stream, b.parent, b.flags, H, W);
   hipLaunchKernelGGL(ccl_count_roots_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, b.parent, n, b.blocksum);
   hipLaunchKernelGGL(ccl_scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, b.blocksum, nblocks, b.n_labels);
   hipLaunchKernelGGL(ccl_rank_roots_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, b.parent, n, b.blocksum,

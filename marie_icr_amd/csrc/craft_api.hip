@@ -550,21 +550,23 @@ extern "C" int mhip_craft_detect(mhip_craft* m, const uint8_t* page_dev, int h, 
         if (h_labels[i] == k && h_flags[i] != 2) seg[(size_t)(yy - sy) * ww + (xx - sx)] = 255;
       }
     const int ks = 1 + niter, an = ks / 2;
-    if (ks > 1) {   // cv2.dilate with a ks x ks rectangle, anchor ks/2: separable running max
+    if (ks > 1) {   // cv2.dilate with a ks x ks rectangle, anchor ks/2; binary mask -> window sums, O(window)
       tmp.assign(seg.size(), 0);
-      for (int yy = 0; yy < wh; ++yy)
-        for (int xx = 0; xx < ww; ++xx) {
-          uint8_t v = 0;
-          const int lo = std::max(0, xx - an), hi = std::min(ww - 1, xx - an + ks - 1);
-          for (int q = lo; q <= hi; ++q) v = std::max(v, seg[(size_t)yy * ww + q]);
-          tmp[(size_t)yy * ww + xx] = v;
-        }
+      std::vector<int> pre((size_t)std::max(ww, wh) + 1);
       for (int yy = 0; yy < wh; ++yy) {
-        const int lo = std::max(0, yy - an), hi = std::min(wh - 1, yy - an + ks - 1);
+        pre[0] = 0;
+        for (int xx = 0; xx < ww; ++xx) pre[xx + 1] = pre[xx] + (seg[(size_t)yy * ww + xx] ? 1 : 0);
         for (int xx = 0; xx < ww; ++xx) {
-          uint8_t v = 0;
-          for (int q = lo; q <= hi; ++q) v = std::max(v, tmp[(size_t)q * ww + xx]);
-          seg[(size_t)yy * ww + xx] = v;
+          const int lo = std::max(0, xx - an), hi = std::min(ww - 1, xx - an + ks - 1);
+          tmp[(size_t)yy * ww + xx] = (hi >= lo && pre[hi + 1] - pre[lo] > 0) ? 255 : 0;
+        }
+      }
+      for (int xx = 0; xx < ww; ++xx) {
+        pre[0] = 0;
+        for (int yy = 0; yy < wh; ++yy) pre[yy + 1] = pre[yy] + (tmp[(size_t)yy * ww + xx] ? 1 : 0);
+        for (int yy = 0; yy < wh; ++yy) {
+          const int lo = std::max(0, yy - an), hi = std::min(wh - 1, yy - an + ks - 1);
+          seg[(size_t)yy * ww + xx] = (hi >= lo && pre[hi + 1] - pre[lo] > 0) ? 255 : 0;
         }
       }
     }
