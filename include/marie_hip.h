@@ -83,6 +83,20 @@ int mhip_conv2d_nhwc(mhip_ctx* ctx, int precision, const mhip_conv_desc* d, cons
                      const void* in2_dev, const void* w_dev, const float* scale_dev, const float* bias_dev,
                      void* out_dev);
 
+/* ---- crop batcher --------------------------------------------------------------------------- */
+/* One text fragment inside a device buffer: first pixel at base + src_offset, h rows of w pixels, `channels` = 3
+ * (BGR, OpenCV order) or 1 (gray), rows row_stride bytes apart (a fragment may be a window of a whole page). */
+typedef struct mhip_crop_desc {
+  uint64_t src_offset;
+  int32_t h, w, row_stride, channels;
+} mhip_crop_desc;
+/* replaces: MemoryDataset.__getitem__ (BGR -> RGB -> PIL "L", marie/models/icr/memory_dataset.py:40-55) and
+ * AlignCollate/NormalizePAD with keep_ratio_with_pad (marie/models/icr/dataset.py:275-324): every fragment becomes a
+ * 32 x img_w uint8 line — Pillow-exact bicubic resize to height 32 keeping the aspect ratio (width capped at img_w),
+ * last column replicated.  out_dev: uint8 [n][32][img_w].  Scratch comes from the ctx workspace.              */
+int mhip_crop_batch(mhip_ctx* ctx, const uint8_t* base_dev, const mhip_crop_desc* descs_host, int n, int img_w,
+                    uint8_t* out_dev);
+
 /* ---- CRNN-family recognizer: None-VGG-BiLSTM-CTC ---------------------------------- */
 /* replaces: Model(opt) construction, marie/models/icr/model.py:27-68 (Trans=None, Feat=VGG,
  * Seq=BiLSTM, Pred=CTC; imgH=32, input_channel=1, output_channel=512, hidden_size=256).  */
@@ -125,6 +139,17 @@ int mhip_crnn_forward(mhip_crnn* m, const uint8_t* crops_dev, int n, int w, floa
 int mhip_crnn_forward_host(mhip_crnn* m, const uint8_t* crops_host, int n, int w, float* logits_host,
                            int32_t* argmax_host, int32_t* tokens_host, int32_t* lengths_host,
                            float* conf_host);
+/* Crop batcher + forward + decode in one call: fragments described inside base_dev (e.g. word boxes on a page
+ * that is already in HBM) -> host outputs.  replaces: CraftOcrProcessor.recognize_from_fragments' DataLoader +
+ * model + decode loop (marie/document/craft_ocr_processor.py:184-286).                                        */
+int mhip_crnn_forward_crops(mhip_crnn* m, const uint8_t* base_dev, const mhip_crop_desc* descs_host, int n, int img_w,
+                            float* logits_host, int32_t* argmax_host, int32_t* tokens_host, int32_t* lengths_host,
+                            float* conf_host);
+/* Same with the fragments packed back to back in a HOST buffer (src_offset relative to packed_host). */
+int mhip_crnn_forward_fragments_host(mhip_crnn* m, const uint8_t* packed_host, size_t packed_bytes,
+                                     const mhip_crop_desc* descs_host, int n, int img_w, float* logits_host,
+                                     int32_t* argmax_host, int32_t* tokens_host, int32_t* lengths_host,
+                                     float* conf_host);
 /* Bytes of ctx workspace one forward of n lines of width w needs (activations, gate buffers). */
 size_t mhip_crnn_workspace_bytes(mhip_crnn* m, int n, int w);
 /* Algorithmic FLOPs (2*MAC) of one forward of n lines of width w, per kernel id — what

@@ -47,6 +47,9 @@ _SIGNATURES = (
                                C.POINTER(_i), _vp, C.POINTER(C.c_double)]),
     ("mhip_craft_detect_host", _i, [_vp, _vp, _i, _i, _i, C.c_double, C.c_float, C.c_float, C.c_float, _vp, _i,
                                     C.POINTER(_i), _vp, C.POINTER(C.c_double)]),
+    ("mhip_crop_batch", _i, [_vp, _vp, _vp, _i, _i, _vp]),
+    ("mhip_crnn_forward_crops", _i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_crnn_forward_fragments_host", _i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("mhip_crnn_create", _i, [_vp, _i, _i, C.POINTER(_vp)]),
     ("mhip_crnn_destroy", _i, [_vp]),
     ("mhip_crnn_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
@@ -69,6 +72,12 @@ class ConvDesc(C.Structure):
                                          "dil", "Cin1")]
 
 
+class CropDesc(C.Structure):
+    """mirror of ``mhip_crop_desc`` (include/marie_hip.h)"""
+    _fields_ = [("src_offset", C.c_uint64), ("h", C.c_int32), ("w", C.c_int32), ("row_stride", C.c_int32),
+                ("channels", C.c_int32)]
+
+
 POOL_NONE, POOL_2x2, POOL_2x1 = 0, 1, 2
 
 _lib = None
@@ -83,6 +92,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.  If libmarie_hip.so were loaded first it would bring in
+    # the system copy and a later `import torch` a second one: two HIP runtimes in one process, which intermittently
+    # leaves torch with "No HIP GPUs are available".  Loading torch first makes both share torch's runtime (same
+    # SONAME).  Without torch installed the system runtime is used alone.
+    import importlib.util
+    import sys
+
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise MarieHipError(
             f"{LIB_PATH} is missing — the HIP extension is not built; there is no CPU fallback "

@@ -201,6 +201,13 @@ class BoxProcessorCraft:
         prediction_result = {"bboxes": bboxes, "polys": polys, "heatmap": score_text}
         max_h, max_w = image.shape[0], image.shape[1]
         rects = rects_from_boxes(bboxes, max_w, max_h)
+        # Boxes that fall entirely into the /32 canvas padding (right of / below the page) have no pixels to crop;
+        # the reference would die on them inside cv2 (empty snippet, craft_box_processor.py:522-535) — drop them.
+        keep = (rects[:, 0] < max_w) & (rects[:, 1] < max_h) if len(rects) else np.zeros((0,), bool)
+        if len(rects) and not keep.all():
+            rects = rects[keep]
+            prediction_result = {"bboxes": bboxes[keep], "polys": [p for p, k in zip(polys, keep) if k],
+                                 "heatmap": score_text}
         rect_from_poly, fragments, rect_line_numbers = [], [], []
         for x, y, w, h in rects.tolist():
             # crop_poly_low on the expanded axis-aligned polygon == the plain crop of its bounding rect

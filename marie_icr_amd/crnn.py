@@ -11,7 +11,6 @@ libmarie_hip.so; this file only packs inputs and turns token ids into strings.
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 from typing import Dict, List, Optional, Sequence
 
@@ -19,6 +18,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import PREC_F16, PREC_F32, Context, MarieHipError, check
+from .ocr_processor import OcrProcessor
 from .weights import CRNN_CHARSET, strip_module_prefix
 
 IMG_H = 32
@@ -89,6 +89,49 @@ class CrnnModel:
               "mhip_crnn_forward_host")
         return {"logits": logits, "argmax": argmax, "tokens": tokens, "lengths": lengths, "confidence": conf}
 
+    def _outputs(self, n: int, w: int, want_logits: bool):
+        t = self.seq_len(w)
+        return (np.empty((n, t, self.num_class), np.float32) if want_logits else None, np.empty((n, t), np.int32),
+                np.empty((n, t), np.int32), np.empty((n,), np.int32), np.empty((n,), np.float32))
+
+    def forward_fragments_host(self, images: Sequence[np.ndarray], img_w: int, want_logits: bool = False):
+        """Arbitrary-size BGR/gray fragments -> GPU crop batcher (Pillow-exact bicubic to 32 x img_w) -> forward."""
+        n = len(images)
+        logits, argmax, tokens, lengths, conf = self._outputs(n, img_w, want_logits)
+        if n:
+            packed, descs = pack_fragments(images)
+            vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)  # noqa: E731
+            check(self.ctx.h,
+                  self.lib.mhip_crnn_forward_fragments_host(self.h, vp(packed), packed.size, descs, n, int(img_w),
+                                                            vp(logits), vp(argmax), vp(tokens), vp(lengths), vp(conf)),
+                  "mhip_crnn_forward_fragments_host")
+        return {"logits": logits, "argmax": argmax, "tokens": tokens, "lengths": lengths, "confidence": conf}
+
+    def forward_rects_device(self, page_ptr: int, page_h: int, page_w: int, rects_xywh: np.ndarray, img_w: int,
+                             channels: int = 3, inclusive: bool = True, want_logits: bool = False):
+        """Fragments given as boxes on a page that already lives in HBM (uint8 [page_h][page_w][channels]).
+        ``inclusive`` reproduces the detector's crop rule rows y..y+h, cols x..x+w (craft_box_processor.py:42-73)."""
+        from ._lib import CropDesc
+
+        rects = np.asarray(rects_xywh, np.int64).reshape(-1, 4)
+        n = len(rects)
+        logits, argmax, tokens, lengths, conf = self._outputs(n, img_w, want_logits)
+        if n:
+            descs = (CropDesc * n)()
+            ext = 1 if inclusive else 0
+            for i, (x, y, w, h) in enumerate(rects.tolist()):
+                x1, y1 = min(page_w, x + w + ext), min(page_h, y + h + ext)
+                x, y = max(0, x), max(0, y)
+                if x1 <= x or y1 <= y:
+                    raise ValueError(f"rect {i} is empty on a {page_w}x{page_h} page")
+                descs[i] = CropDesc((y * page_w + x) * channels, y1 - y, x1 - x, page_w * channels, channels)
+            vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)  # noqa: E731
+            check(self.ctx.h,
+                  self.lib.mhip_crnn_forward_crops(self.h, C.c_void_p(page_ptr), descs, n, int(img_w), vp(logits),
+                                                   vp(argmax), vp(tokens), vp(lengths), vp(conf)),
+                  "mhip_crnn_forward_crops")
+        return {"logits": logits, "argmax": argmax, "tokens": tokens, "lengths": lengths, "confidence": conf}
+
     def forward_device(self, crops_ptr: int, n: int, w: int, logits_ptr: int, argmax_ptr: int, tokens_ptr: int,
                        lengths_ptr: int, conf_ptr: int):
         """All-device entry (pointers are HBM addresses); enqueues on the ctx stream, no sync."""
@@ -135,35 +178,31 @@ def tokens_to_text_fast(tokens: np.ndarray, lengths: np.ndarray, charset: str) -
     return [raw[i * t:i * t + int(ln)].decode("ascii") for i, ln in enumerate(lengths)]
 
 
-def align_collate_u8(images: Sequence[np.ndarray], img_w: int) -> np.ndarray:
-    """Host-side crop batcher: BGR fragment -> grayscale -> height 32 keeping aspect ratio
-    (PIL bicubic) -> right-pad to ``img_w`` by replicating the last column.
+def pack_fragments(images: Sequence[np.ndarray]):
+    """Pack HxWx3 (BGR) / HxW (gray) uint8 fragments back to back for one H2D copy.
+    Returns (packed uint8 buffer, ctypes array of CropDesc)."""
+    from ._lib import CropDesc
 
-    reference: MemoryDataset.__getitem__ (marie/models/icr/memory_dataset.py:17-55: BGR->RGB->PIL->"L")
-    and AlignCollate/NormalizePAD with keep_ratio_with_pad (marie/models/icr/dataset.py:275-324).  The
-    reference replicates the last *normalised* column; replicating the uint8 column first is identical
-    because the normalisation is per pixel.
-    """
-    from PIL import Image
-
-    out = np.empty((len(images), IMG_H, img_w), np.uint8)
+    n = len(images)
+    descs = (CropDesc * n)()
+    arrs = []
+    off = 0
     for i, im in enumerate(images):
         a = np.asarray(im)
-        if a.ndim == 3:
-            pil = Image.fromarray(np.ascontiguousarray(a[:, :, ::-1])).convert("L")  # BGR -> RGB -> L
-        else:
-            pil = Image.fromarray(a).convert("L")
-        w, h = pil.size
-        ratio = w / float(h)
-        rw = img_w if math.ceil(IMG_H * ratio) > img_w else max(1, math.ceil(IMG_H * ratio))
-        g = np.asarray(pil.resize((rw, IMG_H), Image.BICUBIC), dtype=np.uint8)
-        out[i, :, :rw] = g
-        if rw < img_w:
-            out[i, :, rw:] = g[:, rw - 1:rw]
-    return out
+        if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3) or a.size == 0:
+            raise ValueError(f"fragment {i} must be a non-empty uint8 HxWx3 or HxW array, got {a.dtype} {a.shape}")
+        ch = 3 if a.ndim == 3 else 1
+        h, w = a.shape[:2]
+        descs[i] = CropDesc(off, h, w, w * ch, ch)
+        arrs.append(a)
+        off += h * w * ch
+    packed = np.empty(off, np.uint8)
+    for d, a in zip(descs, arrs):
+        packed[d.src_offset:d.src_offset + a.size] = a.reshape(-1)
+    return packed, descs
 
 
-class CrnnOcrProcessor:
+class CrnnOcrProcessor(OcrProcessor):
     """Drop-in for the reference's CRNN-family ``OcrProcessor``
     (marie/document/craft_ocr_processor.py:26; abstract surface marie/document/ocr_processor.py:34-96).
 
@@ -175,6 +214,7 @@ class CrnnOcrProcessor:
                  *, state: Optional[Dict[str, np.ndarray]] = None, character: str = CRNN_CHARSET,
                  img_w: int = 256, precision: str = "f16", device_id: int = 0,
                  model_name: str = "None-VGG-BiLSTM-CTC", ctx: Optional[Context] = None, **kwargs) -> None:
+        super().__init__(work_dir, cuda)
         if not cuda:
             raise MarieHipError("CrnnOcrProcessor is the MI355X path; cuda=False has no implementation here")
         if img_w % 4 or img_w < 8:
@@ -183,7 +223,7 @@ class CrnnOcrProcessor:
         self.cuda = cuda
         self.character = character
         self.img_w = int(img_w)
-        self.batch_size = int(kwargs.get("batch_size", 1024))
+        self.batch_size = int(kwargs.get("batch_size", 4096))
         self.ctx = ctx or Context(device_id)
         if state is None:
             if models_dir is None:
@@ -204,8 +244,7 @@ class CrnnOcrProcessor:
         results: List[Dict[str, object]] = []
         for start in range(0, len(images), self.batch_size):
             batch = images[start:start + self.batch_size]
-            crops = align_collate_u8(batch, self.img_w)
-            out = self.model.forward_host(crops)
+            out = self.model.forward_fragments_host(batch, self.img_w)
             texts = tokens_to_text(out["tokens"], out["lengths"], self.character)
             for k, (text, conf) in enumerate(zip(texts, out["confidence"].tolist())):
                 results.append({"confidence": conf, "text": text, "id": f"img-{start + k}"})

@@ -18,7 +18,8 @@ enum MhipKernelId {
   MHIP_K_CTC_DECODE = 3,  // wave-shuffle argmax + softmax-max + collapse
   MHIP_K_IMAGE_OPS = 4,   // resize / max-pool / bilinear up-sample (HBM-bound, 16 B per lane)
   MHIP_K_CCL = 5,         // score-map binarise + connected components + per-component statistics
-  MHIP_K_COUNT = 6
+  MHIP_K_CROP_BATCH = 6,  // fragment -> gray -> Pillow-exact bicubic to height 32 -> replicate pad
+  MHIP_K_COUNT = 7
 };
 
 struct ProfSlot {
@@ -134,3 +135,9 @@ void mhip_ccl_carve(char* base, int H, int W, CclBuffers* out);
 int mhip_launch_ccl(mhip_ctx* ctx, const float* scores, int H, int W, float low_text, float link_thr,
                     const CclBuffers& b);
 float mhip_ordered_bits_to_float(int bits);
+
+// ------------------------------------------------------------------ crop batcher (crop_batch.hip)
+int mhip_crop_resized_width(int w, int h, int img_h, int img_w);
+size_t mhip_crop_scratch_bytes(const mhip_crop_desc* descs, int n, int img_h, int img_w);
+int mhip_launch_crop_batch(mhip_ctx* ctx, const uint8_t* base_dev, const mhip_crop_desc* descs, int n, int img_h,
+                           int img_w, void* scratch_dev, uint8_t* out_dev);

@@ -21,8 +21,8 @@ int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "lstm_rec",
-                                                 "ctc_decode", "image_ops",  "ccl"};
+static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "lstm_rec",  "ctc_decode",
+                                                 "image_ops",  "ccl",        "crop_batch"};
 
 extern "C" int mhip_kernel_count(void) { return MHIP_K_COUNT; }
 extern "C" const char* mhip_kernel_name(int k) { return (k >= 0 && k < MHIP_K_COUNT) ? kKernelNames[k] : ""; }
@@ -642,4 +642,77 @@ extern "C" int mhip_crnn_forward_host(mhip_crnn* m, const uint8_t* crops_h, int 
   MHIP_HIP(ctx, hipMemcpyAsync(conf_h, ws + o_cf, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MHIP_OK;
+}
+
+// ======================================================================= crop batcher + composite entries
+extern "C" int mhip_crop_batch(mhip_ctx* ctx, const uint8_t* base_dev, const mhip_crop_desc* descs, int n, int img_w,
+                               uint8_t* out_dev) {
+  if (!ctx || !descs || n < 1 || img_w < 1) return MHIP_EINVAL;
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t sb = mhip_crop_scratch_bytes(descs, n, 32, img_w);
+  int rc = mhip_ensure_workspace(ctx, sb);
+  if (rc) return rc;
+  return mhip_launch_crop_batch(ctx, base_dev, descs, n, 32, img_w, ctx->ws, out_dev);
+}
+
+namespace {
+
+int forward_crops_impl(mhip_crnn* m, const uint8_t* base_dev, const uint8_t* packed_host, size_t packed_bytes,
+                       const mhip_crop_desc* descs, int n, int img_w, float* logits_h, int32_t* argmax_h,
+                       int32_t* tokens_h, int32_t* lengths_h, float* conf_h) {
+  int rc = check_shape(m, n, img_w);
+  if (rc) return rc;
+  mhip_ctx* ctx = m->ctx;
+  if (!descs || !argmax_h || !tokens_h || !lengths_h || !conf_h) return mhip_fail(ctx, MHIP_EINVAL, "crnn: null buffer");
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const int T = img_w / 4 - 1, C = m->num_class;
+  const Plan p = make_plan(m, n, img_w);
+  size_t o = p.total;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = align_up(o + bytes, 4096);
+    return at;
+  };
+  const size_t it_b = (size_t)n * T * 4, lg_b = (size_t)n * T * C * 4;
+  const size_t o_crops = take((size_t)n * 32 * img_w), o_scr = take(mhip_crop_scratch_bytes(descs, n, 32, img_w));
+  const size_t o_lg = take(logits_h ? lg_b : 16), o_am = take(it_b), o_tk = take(it_b), o_ln = take((size_t)n * 4),
+               o_cf = take((size_t)n * 4);
+  const size_t o_pk = packed_host ? take(packed_bytes) : 0;
+  rc = mhip_ensure_workspace(ctx, o);
+  if (rc) return rc;
+  char* ws = (char*)ctx->ws;
+  if (packed_host) {
+    MHIP_HIP(ctx, hipMemcpyAsync(ws + o_pk, packed_host, packed_bytes, hipMemcpyHostToDevice, ctx->stream));
+    base_dev = (const uint8_t*)(ws + o_pk);
+  }
+  rc = mhip_launch_crop_batch(ctx, base_dev, descs, n, 32, img_w, ws + o_scr, (uint8_t*)(ws + o_crops));
+  if (rc) return rc;
+  rc = mhip_crnn_forward(m, (const uint8_t*)(ws + o_crops), n, img_w, logits_h ? (float*)(ws + o_lg) : nullptr,
+                         (int32_t*)(ws + o_am), (int32_t*)(ws + o_tk), (int32_t*)(ws + o_ln), (float*)(ws + o_cf));
+  if (rc) return rc;
+  if (logits_h) MHIP_HIP(ctx, hipMemcpyAsync(logits_h, ws + o_lg, lg_b, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(argmax_h, ws + o_am, it_b, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(tokens_h, ws + o_tk, it_b, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(lengths_h, ws + o_ln, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(conf_h, ws + o_cf, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int mhip_crnn_forward_crops(mhip_crnn* m, const uint8_t* base_dev, const mhip_crop_desc* descs, int n,
+                                       int img_w, float* logits_h, int32_t* argmax_h, int32_t* tokens_h,
+                                       int32_t* lengths_h, float* conf_h) {
+  if (!m || !base_dev) return MHIP_EINVAL;
+  return forward_crops_impl(m, base_dev, nullptr, 0, descs, n, img_w, logits_h, argmax_h, tokens_h, lengths_h, conf_h);
+}
+
+extern "C" int mhip_crnn_forward_fragments_host(mhip_crnn* m, const uint8_t* packed_host, size_t packed_bytes,
+                                                const mhip_crop_desc* descs, int n, int img_w, float* logits_h,
+                                                int32_t* argmax_h, int32_t* tokens_h, int32_t* lengths_h,
+                                                float* conf_h) {
+  if (!m || !packed_host || !packed_bytes) return MHIP_EINVAL;
+  return forward_crops_impl(m, nullptr, packed_host, packed_bytes, descs, n, img_w, logits_h, argmax_h, tokens_h,
+                            lengths_h, conf_h);
 }

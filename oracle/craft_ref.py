@@ -365,4 +365,6 @@ def detect_page(img_u8: np.ndarray, st, text_threshold=0.7, link_threshold=0.45,
     y, _ = craft_forward(x, st)
     boxes, _, _ = get_det_boxes(y[0, :, :, 0], y[0, :, :, 1], text_threshold, link_threshold, low_text)
     rects = boxes_to_rects(boxes, ratio, w, h)
+    # boxes lying entirely in the /32 canvas padding have no page pixels (the reference would raise inside cv2)
+    rects = rects[(rects[:, 0] < w) & (rects[:, 1] < h)] if len(rects) else rects
     return rects, y

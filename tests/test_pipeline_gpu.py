@@ -1,0 +1,107 @@
+"""GPU: crop batcher bit-exact vs Pillow (through the oracle restatement pinned to it), and the whole
+detect -> crop -> recognize path behind the OcrEngine surface vs the CPU oracle pipeline."""
+import numpy as np
+import pytest
+
+from marie_icr_amd.weights import CRNN_CHARSET, make_craft_state, make_crnn_state, make_page_bgr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from marie_icr_amd._lib import Context
+
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _rand_crop(rng, h, w, ch=3):
+    base = rng.integers(0, 256, size=(h // 3 + 1, w // 3 + 1, ch)).astype(np.float32)
+    up = np.repeat(np.repeat(base, 3, 0), 3, 1)[:h, :w]
+    a = np.clip(up + rng.integers(-20, 21, size=(h, w, ch)), 0, 255).astype(np.uint8)
+    return a if ch == 3 else a[:, :, 0]
+
+
+@pytest.mark.parametrize("img_w", [256, 100])
+def test_crop_batcher_is_pillow_exact(ctx, img_w):
+    import torch
+
+    from marie_icr_amd.crnn import pack_fragments
+    from oracle import pil_resample as pr
+
+    rng = np.random.default_rng(img_w)
+    shapes = [(38, 120), (25, 60), (48, 700), (32, 256), (17, 9), (90, 30), (41, 333), (1, 50), (64, 1), (33, 2000)]
+    crops = [_rand_crop(rng, h, w) for h, w in shapes] + [_rand_crop(rng, 29, 77, ch=1)]
+    packed, descs = pack_fragments(crops)
+    d_in = torch.from_numpy(packed).cuda()
+    d_out = torch.empty((len(crops), 32, img_w), dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    from marie_icr_amd._lib import check
+    import ctypes as C
+
+    check(ctx.h, ctx.lib.mhip_crop_batch(ctx.h, C.c_void_p(d_in.data_ptr()), descs, len(crops), img_w,
+                                         C.c_void_p(d_out.data_ptr())), "mhip_crop_batch")
+    torch.cuda.synchronize()
+    ref = pr.align_collate_pil(crops, img_w)          # Pillow itself
+    assert np.array_equal(d_out.cpu().numpy(), ref)
+    ctx.set_stream(None)
+
+
+def test_engine_full_page_vs_oracle(ctx):
+    from marie_icr_amd.box_processor import PSMode
+    from marie_icr_amd.craft import BoxProcessorCraft
+    from marie_icr_amd.crnn import CrnnOcrProcessor
+    from marie_icr_amd.ocr_engine import CoordinateFormat, MarieHipOcrEngine
+    from oracle import craft_ref, crnn_numpy
+    from oracle import pil_resample as pr
+
+    dst, rst = make_craft_state(5), make_crnn_state(0)
+    pages = [make_page_bgr(5, 300, 240), make_page_bgr(6, 260, 330)]
+    bp = BoxProcessorCraft(state=dst, precision="f32", ctx=ctx)
+    rec = CrnnOcrProcessor(state=rst, precision="f32", img_w=128, ctx=ctx)
+    eng = MarieHipOcrEngine(box_processor=bp, default_ocr_processor=rec)
+    results = eng.extract(pages, PSMode.SPARSE, CoordinateFormat.XYWH)
+    assert len(results) == 2
+    for pi, (page, res) in enumerate(zip(pages, results)):
+        assert res["meta"]["page"] == pi and res["meta"]["format"] == "xywh"
+        assert res["meta"]["imageSize"] == {"width": page.shape[1], "height": page.shape[0]}
+        # ---- oracle pipeline on the same page
+        rects, _ = craft_ref.detect_page(page, dst)
+        frags = craft_ref.crop_fragments(page, rects)
+        words = res["words"]
+        assert len(words) == len(rects)
+        if len(rects) == 0:
+            continue
+        crops = pr.align_collate_u8(frags, 128)
+        logits, idx, texts, conf = crnn_numpy.recognize_crops_u8(crops, rst, CRNN_CHARSET)
+        order = np.argsort(rects[:, 0])                  # OcrProcessor.recognize orders words by x
+        s = np.sort(logits, axis=2)
+        safe = ((s[:, :, -1] - s[:, :, -2]) > 2e-3).all(axis=1)
+        for wi, (word, oi) in enumerate(zip(words, order)):
+            assert word["id"] == wi and word["line"] == -1
+            assert list(word["box"]) == rects[oi].tolist()
+            if safe[oi]:
+                assert word["text"] == texts[oi]
+                assert abs(word["confidence"] - round(float(conf[oi]), 3)) <= 2e-3
+        # one line group (every word has line -1), text = words joined in x order
+        assert len(res["lines"]) == 1
+        assert res["lines"][0]["wordids"] == list(range(len(words)))
+        if safe.all():
+            assert res["lines"][0]["text"] == " ".join(texts[oi] for oi in order)
+    # XYXY conversion and the region path
+    r2 = eng.extract(pages[:1], PSMode.SPARSE, CoordinateFormat.XYXY)
+    for a, b in zip(results[0]["words"], r2[0]["words"]):
+        x, y, w, h = a["box"]
+        assert list(b["box"]) == [x, y, x + w, y + h]
+    reg = eng.extract(pages[:1], PSMode.RAW_LINE, CoordinateFormat.XYWH,
+                      regions=[{"id": 7, "pageIndex": 0, "x": 10, "y": 20, "w": 120, "h": 30},
+                               {"id": 8, "pageIndex": 0, "x": 0, "y": 0, "w": 0, "h": 10}])
+    # reference quirk kept: a rejected region is reported at once AND again when the word count no longer matches
+    # the region count, which also blanks the surviving region (ocr_engine.py:276-283,375-389)
+    ids = sorted(r["id"] for r in reg["regions"])
+    assert ids == [7, 8, 8] and len(reg["extended"]) == 1
+    ok = eng.extract(pages[:1], PSMode.RAW_LINE, CoordinateFormat.XYWH,
+                     regions=[{"id": 7, "pageIndex": 0, "x": 10, "y": 20, "w": 120, "h": 30}])
+    assert [r["id"] for r in ok["regions"]] == [7] and isinstance(ok["regions"][0]["text"], str)
