@@ -5,22 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): the CRNN recognizer (None-VGG-BiLSTM-CTC) on a batch of
-1024 pre-cropped 32x256 grayscale text lines per GPU, seeded random weights.  One *step* = one
-pass of the recognizer hot path over one such batch: uint8 crops resident in HBM -> normalise ->
-conv stack -> BiLSTM x2 -> prediction -> greedy CTC decode + confidence -> token ids / lengths /
-confidences copied to pinned host memory and turned into strings (one step behind the GPU).
+Default workload ``pages`` (BASELINE.json metric: pages/sec on 2550x3300 pages, ~40 lines/page): one *step* = one
+pass of detect -> crop -> recognize over a batch of ``--pages`` synthetic 2550x3300x3 uint8 pages per GPU that are
+already resident in HBM:
+    CRAFT detector (cv2-exact resize to the 1970x2550 canvas, normalise, VGG16-BN + U-net, score maps) ->
+    GPU threshold + connected components + statistics -> host box finalisation (minAreaRect etc.) ->
+    crop batcher (Pillow-exact bicubic to 32 x 256) -> CRNN recognizer (None-VGG-BiLSTM-CTC) -> greedy CTC decode ->
+    token ids / confidences to pinned host memory -> strings.
+Fixed recognizer work: the detector runs and is timed in full, the recognizer consumes the page
+generator's 40 ground-truth line boxes per page (``--crops detector`` feeds the detector's own boxes instead; with
+random weights their number is arbitrary, so that mode is the secondary number).  Seeded random weights.
 
-Multi-GPU: lines/pages are independent, so each rank owns its own batch — weak
-scaling, no data-path collective.  Rank 0 packs the weights and the packed arena is broadcast
-once over RCCL/xGMI at start-up; the timed region is bracketed by barrier + synchronize and the
-maximum over ranks is reported.
+``--workload crnn`` = BASELINE configs[1]: the CRNN recognizer alone on 1024 pre-cropped 32x256 lines per GPU.
 
-Rank 0 prints ONE JSON line.  ``roofline`` covers the dominant kernel (conv_igemm, MFMA-bound):
-its algorithmic FLOPs (mhip_crnn_kernel_flops, = SURVEY.md §8d's per-line figure x lines) divided
-by its device time, measured live with HIP events on the launch stream inside the timed steps.
-``cpu_baseline`` times the CPU oracle (oracle/crnn_torch.py — the same torch CPU ops the reference
-executes) on rank 0's host cores on a bounded sample of the same workload.
+Multi-GPU: pages are independent, so each rank owns its own pages — weak scaling, no data-path
+collective.  Rank 0 packs the weights and the packed arenas are broadcast once over RCCL/xGMI at start-up; the timed
+region is bracketed by barrier + synchronize and the maximum over ranks is reported.
+
+Rank 0 prints ONE JSON line.  ``roofline`` covers the dominant kernel (conv_igemm, MFMA-bound): algorithmic FLOPs of
+all its launches in a step (mhip_craft_kernel_flops + mhip_crnn_kernel_flops: real channel counts, 2*MAC) divided by
+its summed device time, measured live with HIP events on the launch stream inside the timed steps.  ``cpu_baseline``
+times the CPU oracle (torch CPU ops — what the reference executes on a CPU host — plus the reference's numpy
+post-processing restated) on rank 0's host cores on a bounded sample of the same workload.
 """
 from __future__ import annotations
 
@@ -37,21 +43,27 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 LINES_PER_PAGE = 40          # BASELINE.json metric: "~40 lines/page"
+PAGE_H, PAGE_W = 3300, 2550  # 300-dpi letter page
 PEAK_MFMA_TFLOPS_F16 = 2500  # dense f16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_MFMA_TFLOPS_F32 = 157.3
+THRESH = (0.7, 0.45, 0.3)    # psm_sparse: text_threshold, link_threshold, low_text
 
 
-def cpu_baseline(state, charset, img_w, target_s=12.0):
-    """Time the CPU oracle on a bounded sample (rank 0, N=1 only)."""
+def host_cores():
+    try:
+        c = len(os.sched_getaffinity(0))
+    except AttributeError:
+        c = os.cpu_count() or 1
+    return max(1, min(c, 64))
+
+
+def cpu_baseline_crnn(state, charset, img_w, target_s=12.0):
+    """Time the CPU oracle of the recognizer on a bounded sample (rank 0, N=1 only)."""
     from marie_icr_amd.weights import make_crnn_input
     from oracle import crnn_numpy
     from oracle.crnn_torch import TorchCrnnOracle
 
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    cores = host_cores()
     o = TorchCrnnOracle(state, threads=cores)
     probe = make_crnn_input(1, 64, 32, img_w)
     x = crnn_numpy.normalize_u8(probe)
@@ -73,12 +85,43 @@ def cpu_baseline(state, charset, img_w, target_s=12.0):
                       f"oracle/crnn_torch.py (torch CPU ops), {dt:.1f} s"}
 
 
+def cpu_baseline_pages(craft_state, crnn_state, charset, img_w, n_lines):
+    """One full page through the CPU oracle pipeline (rank 0, N=1 only): torch-CPU CRAFT forward, the reference's
+    numpy post-processing restated, Pillow crop batcher, torch-CPU CRNN.  ~15-30 s of CPU work."""
+    import torch
+
+    from marie_icr_amd.weights import make_page_bgr, page_line_boxes
+    from oracle import craft_ref, crnn_numpy
+    from oracle import pil_resample as pr
+    from oracle.crnn_torch import TorchCrnnOracle
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    page = make_page_bgr(999, PAGE_H, PAGE_W, n_lines=n_lines)
+    lines = page_line_boxes(PAGE_H, PAGE_W, n_lines)
+    rec = TorchCrnnOracle(crnn_state, threads=cores)
+    t0 = time.perf_counter()
+    rects, _ = craft_ref.detect_page(page, craft_state, *THRESH)
+    t1 = time.perf_counter()
+    frags = [page[y:y + h + 1, x:x + w + 1] for x, y, w, h in lines.tolist()]
+    crops = pr.align_collate_pil(frags, img_w)
+    rec.decode(rec.logits(crnn_numpy.normalize_u8(crops)), charset)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "pages/s", "cores": cores, "kind": "port",
+            "sample": f"1 of the same seeded {PAGE_W}x{PAGE_H} pages, fp32: detector {t1 - t0:.1f} s "
+                      f"({len(rects)} boxes; torch CPU forward + the reference's per-component numpy loop), "
+                      f"{n_lines} line crops + recognizer {t2 - t1:.2f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--lines", type=int, default=1024, help="lines per GPU per step")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["pages", "crnn"], default="pages")
+    ap.add_argument("--pages", type=int, default=8, help="pages per GPU per step (workload pages)")
+    ap.add_argument("--crops", choices=["lines", "detector"], default="lines")
+    ap.add_argument("--lines", type=int, default=1024, help="lines per GPU per step (workload crnn)")
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--precision", choices=["f16", "f32"], default="f16")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-kernel HIP events in the timed region")
@@ -104,59 +147,101 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     from marie_icr_amd._lib import PREC_F16, PREC_F32, Context
+    from marie_icr_amd.craft import CraftModel, adjust_result_coordinates, rects_from_boxes
     from marie_icr_amd.crnn import CrnnModel, tokens_to_text_fast
-    from marie_icr_amd.weights import CRNN_CHARSET, make_crnn_input, make_crnn_state
+    from marie_icr_amd.dist import broadcast_arena
+    from marie_icr_amd.weights import (CRNN_CHARSET, make_craft_bench_state, make_crnn_input, make_crnn_state,
+                                       make_page_bgr, page_line_boxes)
 
     prec = PREC_F16 if args.precision == "f16" else PREC_F32
     ctx = Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
-    # ---- weights: rank 0 packs, everyone else receives the packed arena over RCCL ----------
-    state = make_crnn_state(0)
-    if world > 1:
-        model = CrnnModel(ctx, state if rank == 0 else None, num_class=95, precision=prec)
-        if rank != 0:
-            model.alloc_arena()
-        from marie_icr_amd.dist import broadcast_arena
+    # ---- weights: rank 0 packs, everyone else receives the packed arenas over RCCL ----------
+    crnn_state = make_crnn_state(0)
+    craft_state = make_craft_bench_state() if args.workload == "pages" else None
 
-        broadcast_arena(model, ctx, dist, src=0)
-    else:
-        model = CrnnModel(ctx, state, num_class=95, precision=prec)
+    def load(cls, state, **kw):
+        if world > 1:
+            m = cls(ctx, state if rank == 0 else None, precision=prec, **kw)
+            if rank != 0:
+                m.alloc_arena()
+            broadcast_arena(m, ctx, dist, src=0)
+            return m
+        return cls(ctx, state, precision=prec, **kw)
 
-    n, w = args.lines, args.width
-    T = model.seq_len(w)
-    crops = torch.from_numpy(make_crnn_input(1000 + rank, n, 32, w)).cuda()
-    d_arg = torch.empty((n, T), dtype=torch.int32, device="cuda")
-    d_tok = [torch.empty((n, T), dtype=torch.int32, device="cuda") for _ in range(2)]
-    d_len = [torch.empty((n,), dtype=torch.int32, device="cuda") for _ in range(2)]
-    d_cnf = [torch.empty((n,), dtype=torch.float32, device="cuda") for _ in range(2)]
-    h_tok = [torch.empty((n, T), dtype=torch.int32).pin_memory() for _ in range(2)]
-    h_len = [torch.empty((n,), dtype=torch.int32).pin_memory() for _ in range(2)]
-    h_cnf = [torch.empty((n,), dtype=torch.float32).pin_memory() for _ in range(2)]
-    ev = [torch.cuda.Event() for _ in range(2)]
+    rec = load(CrnnModel, crnn_state, num_class=95)
+    det = load(CraftModel, craft_state) if args.workload == "pages" else None
+
+    w = args.width
+    T = rec.seq_len(w)
     last_texts = [None]
+    units_per_step = 0
+    stats = {"boxes": 0, "crops": 0}
 
-    def step(i):
-        b = i & 1
-        model.forward_device(crops.data_ptr(), n, w, 0, d_arg.data_ptr(), d_tok[b].data_ptr(),
-                             d_len[b].data_ptr(), d_cnf[b].data_ptr())
-        h_tok[b].copy_(d_tok[b], non_blocking=True)
-        h_len[b].copy_(d_len[b], non_blocking=True)
-        h_cnf[b].copy_(d_cnf[b], non_blocking=True)
-        ev[b].record(stream)
+    if args.workload == "crnn":
+        n = args.lines
+        units_per_step = n
+        crops = torch.from_numpy(make_crnn_input(1000 + rank, n, 32, w)).cuda()
+        d_arg = torch.empty((n, T), dtype=torch.int32, device="cuda")
+        d_tok = [torch.empty((n, T), dtype=torch.int32, device="cuda") for _ in range(2)]
+        d_len = [torch.empty((n,), dtype=torch.int32, device="cuda") for _ in range(2)]
+        d_cnf = [torch.empty((n,), dtype=torch.float32, device="cuda") for _ in range(2)]
+        h_tok = [torch.empty((n, T), dtype=torch.int32).pin_memory() for _ in range(2)]
+        h_len = [torch.empty((n,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        h_cnf = [torch.empty((n,), dtype=torch.float32).pin_memory() for _ in range(2)]
+        ev = [torch.cuda.Event() for _ in range(2)]
 
-    def collect(i):
-        b = i & 1
-        ev[b].synchronize()
-        last_texts[0] = tokens_to_text_fast(h_tok[b].numpy(), h_len[b].numpy(), CRNN_CHARSET)
+        def step(i):
+            b = i & 1
+            rec.forward_device(crops.data_ptr(), n, w, 0, d_arg.data_ptr(), d_tok[b].data_ptr(), d_len[b].data_ptr(),
+                               d_cnf[b].data_ptr())
+            h_tok[b].copy_(d_tok[b], non_blocking=True)
+            h_len[b].copy_(d_len[b], non_blocking=True)
+            h_cnf[b].copy_(d_cnf[b], non_blocking=True)
+            ev[b].record(stream)
 
-    def run(k):
-        for i in range(k):
-            step(i)
-            if i > 0:
-                collect(i - 1)     # host string decode of step i-1 overlaps GPU step i
-        collect(k - 1)
+        def collect(i):
+            b = i & 1
+            ev[b].synchronize()
+            last_texts[0] = tokens_to_text_fast(h_tok[b].numpy(), h_len[b].numpy(), CRNN_CHARSET)
+
+        def run(k):
+            for i in range(k):
+                step(i)
+                if i > 0:
+                    collect(i - 1)     # host string decode of step i-1 overlaps GPU step i
+            collect(k - 1)
+    else:
+        P = args.pages
+        units_per_step = P
+        host_pages = np.stack([make_page_bgr(1000 + rank * 97 + i, PAGE_H, PAGE_W, n_lines=LINES_PER_PAGE)
+                               for i in range(min(P, 4))])
+        pages = torch.from_numpy(host_pages[np.arange(P) % len(host_pages)]).cuda()     # [P][H][W][3] in HBM
+        page_bytes = PAGE_H * PAGE_W * 3
+        gt = page_line_boxes(PAGE_H, PAGE_W, LINES_PER_PAGE)
+
+        def run(k):
+            for _ in range(k):
+                rect_list = []
+                for pi in range(P):
+                    boxes, ratio = det.detect_device(pages.data_ptr() + pi * page_bytes, PAGE_H, PAGE_W, *THRESH)
+                    bboxes = adjust_result_coordinates(boxes, 1 / ratio, 1 / ratio)
+                    rects = rects_from_boxes(bboxes, PAGE_W, PAGE_H)
+                    rects = rects[(rects[:, 0] < PAGE_W) & (rects[:, 1] < PAGE_H)] if len(rects) else rects
+                    stats["boxes"] += len(rects)
+                    use = gt if args.crops == "lines" else rects
+                    r = use.astype(np.int64).copy()
+                    r[:, 1] += pi * PAGE_H          # the P pages are one [P*H][W][3] image for the crop batcher
+                    rect_list.append(r)
+                allr = np.concatenate(rect_list) if rect_list else np.zeros((0, 4), np.int64)
+                stats["crops"] += len(allr)
+                texts = []
+                for s0 in range(0, len(allr), 4096):
+                    out = rec.forward_rects_device(pages.data_ptr(), P * PAGE_H, PAGE_W, allr[s0:s0 + 4096], w)
+                    texts += tokens_to_text_fast(out["tokens"], out["lengths"], CRNN_CHARSET)
+                last_texts[0] = texts
 
     def fence():
         torch.cuda.synchronize()
@@ -167,6 +252,7 @@ def main():
     run(max(1, args.warmup))
     ktime = not args.no_kernel_timing
     fence()
+    stats["boxes"] = stats["crops"] = 0
     if ktime:
         ctx.profile_reset()
         ctx.profile_enable(True)
@@ -186,44 +272,64 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        lines_per_s = world * n * args.steps / dt
-        out = {
-            "metric": "lines/sec (CRNN recognizer stage of the pages/sec path)",
-            "value": lines_per_s,
-            "unit": "lines/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.precision,
-            "data": "synthetic",
-            "config": {
-                "workload": f"BASELINE configs[1]: CRNN recognizer only (None-VGG-BiLSTM-CTC), {n} pre-cropped "
-                            f"32x{w} u8 lines per GPU per step, seeded random weights, greedy CTC decode to strings",
-                "lines_per_gpu_per_step": n, "img_w": w, "parallelism": f"dp{world} (independent batches)",
-                "pages_per_sec_equiv": lines_per_s / LINES_PER_PAGE,
-                "pages_note": "recognizer stage only at 40 lines/page; the detector is not in this number",
-            },
-        }
+        rate = world * units_per_step * args.steps / dt
+        if args.workload == "pages":
+            P = args.pages
+            crops_pp = stats["crops"] / (args.steps * P)
+            out = {
+                "metric": "pages/sec (2550x3300, ~40 lines/page)",
+                "value": rate, "unit": "pages/s",
+                "config": {
+                    "workload": f"detect->crop->recognize, {P} synthetic {PAGE_W}x{PAGE_H}x3 u8 pages per GPU per step "
+                                f"resident in HBM: CRAFT detector (box_segmentation_mode 2) + CRNN recognizer "
+                                f"(None-VGG-BiLSTM-CTC, 32x{w} crops), seeded random weights; recognizer input = "
+                                + ("the generator's 40 ground-truth line boxes per page (fixed work)"
+                                   if args.crops == "lines" else "the detector's own boxes"),
+                    "pages_per_gpu_per_step": P, "crops_per_page": crops_pp,
+                    "detector_boxes_per_page": stats["boxes"] / (args.steps * P),
+                    "parallelism": f"dp{world} (independent pages)",
+                    "not_in_this_number": "DiT Mask R-CNN detector and TrOCR recognizer (BASELINE configs[2..4]) "
+                                          "are not built yet",
+                },
+            }
+            flops_step = P * det.kernel_flops(PAGE_H, PAGE_W)["conv_igemm"] + \
+                rec.kernel_flops(max(1, int(round(crops_pp * P))), w)["conv_igemm"]
+        else:
+            n = args.lines
+            out = {
+                "metric": "lines/sec (CRNN recognizer stage of the pages/sec path)",
+                "value": rate, "unit": "lines/s",
+                "config": {
+                    "workload": f"BASELINE configs[1]: CRNN recognizer only (None-VGG-BiLSTM-CTC), {n} pre-cropped "
+                                f"32x{w} u8 lines per GPU per step, seeded random weights, greedy CTC decode to strings",
+                    "lines_per_gpu_per_step": n, "img_w": w, "parallelism": f"dp{world} (independent batches)",
+                    "pages_per_sec_equiv": rate / LINES_PER_PAGE,
+                    "pages_note": "recognizer stage only at 40 lines/page; the detector is not in this number",
+                },
+            }
+            flops_step = rec.kernel_flops(n, w)["conv_igemm"]
+        out.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+                    "data": "synthetic"})
         if prof is not None:
-            flops = model.kernel_flops(n, w)
             k = prof["conv_igemm"]
             per_step_ms = k["total_ms"] / args.steps
-            achieved = flops["conv_igemm"] / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
+            achieved = flops_step / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
             peak = PEAK_MFMA_TFLOPS_F16 if args.precision == "f16" else PEAK_MFMA_TFLOPS_F32
             out["roofline"] = {
                 "bound": "mfma", "kernel": "conv_igemm", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": None,
                 "launches_per_step": k["launches"] / args.steps,
                 "avg_launch_ms": k["total_ms"] / max(k["launches"], 1),
-                "algorithmic_gflop_per_step": flops["conv_igemm"] / 1e9,
+                "algorithmic_gflop_per_step": flops_step / 1e9,
             }
-            out["kernels_ms_per_step"] = {name: v["total_ms"] / args.steps for name, v in prof.items()}
+            out["kernels_ms_per_step"] = {name: v["total_ms"] / args.steps for name, v in prof.items() if v["launches"]}
+            out["gpu_busy_frac"] = sum(v["total_ms"] for v in prof.values()) / (1e3 * dt)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(state, CRNN_CHARSET, w)
+            if args.workload == "pages":
+                out["cpu_baseline"] = cpu_baseline_pages(craft_state, crnn_state, CRNN_CHARSET, w, LINES_PER_PAGE)
+            else:
+                out["cpu_baseline"] = cpu_baseline_crnn(crnn_state, CRNN_CHARSET, w)
         out["sample_output"] = last_texts[0][:2] if last_texts[0] else None
         print(json.dumps(out), flush=True)
 

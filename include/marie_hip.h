@@ -172,6 +172,8 @@ int mhip_craft_arena(mhip_craft* m, void** arena_dev, size_t* bytes);
 int mhip_craft_geometry(int h, int w, int canvas_size, double mag_ratio, double* ratio, int* th, int* tw,
                         int* H32, int* W32);
 size_t mhip_craft_workspace_bytes(mhip_craft* m, int h, int w, int canvas_size, double mag_ratio);
+/* Algorithmic FLOPs (2*MAC over the checkpoint's real channel counts) of one forward of an h x w page, per kernel id. */
+double mhip_craft_kernel_flops(mhip_craft* m, int kernel_id, int h, int w, int canvas_size, double mag_ratio);
 /* replaces: get_prediction's resize + normalizeMeanVariance + net(x), craft_box_processor.py:94-110.
  * page_dev uint8 [h][w][3] (channel order as given, the reference feeds BGR) -> scores_dev fp32 [H32/2][W32/2][2]
  * (channel 0 = text/region score, 1 = link/affinity score).                                                  */

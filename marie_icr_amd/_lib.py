@@ -42,6 +42,7 @@ _SIGNATURES = (
     ("mhip_craft_geometry", _i, [_i, _i, _i, C.c_double, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_i),
                                  C.POINTER(_i), C.POINTER(_i)]),
     ("mhip_craft_workspace_bytes", _sz, [_vp, _i, _i, _i, C.c_double]),
+    ("mhip_craft_kernel_flops", C.c_double, [_vp, _i, _i, _i, _i, C.c_double]),
     ("mhip_craft_forward", _i, [_vp, _vp, _i, _i, _i, C.c_double, _vp]),
     ("mhip_craft_detect", _i, [_vp, _vp, _i, _i, _i, C.c_double, C.c_float, C.c_float, C.c_float, _vp, _i,
                                C.POINTER(_i), _vp, C.POINTER(C.c_double)]),

@@ -94,6 +94,26 @@ class CraftModel:
               "mhip_craft_detect_host")
         return self._boxes[:n.value].copy(), scores, ratio.value
 
+    def detect_device(self, page_ptr: int, h: int, w: int, text_threshold: float, link_threshold: float,
+                      low_text: float, canvas_size: Optional[int] = None, mag_ratio: float = 1.0):
+        """Page already in HBM (uint8 [h][w][3] at ``page_ptr``).  Returns (boxes (K,4,2) fp32, ratio)."""
+        canvas = int(canvas_size if canvas_size is not None else w)
+        n = C.c_int()
+        ratio = C.c_double()
+        check(self.ctx.h,
+              self.lib.mhip_craft_detect(self.h, C.c_void_p(page_ptr), int(h), int(w), canvas, float(mag_ratio),
+                                         float(text_threshold), float(link_threshold), float(low_text),
+                                         self._boxes.ctypes.data_as(C.c_void_p), self.max_boxes, C.byref(n),
+                                         C.c_void_p(0), C.byref(ratio)),
+              "mhip_craft_detect")
+        return self._boxes[:n.value].copy(), ratio.value
+
+    def kernel_flops(self, h: int, w: int, canvas_size: Optional[int] = None, mag_ratio: float = 1.0):
+        canvas = int(canvas_size if canvas_size is not None else w)
+        return {self.lib.mhip_kernel_name(k).decode():
+                self.lib.mhip_craft_kernel_flops(self.h, k, int(h), int(w), canvas, float(mag_ratio))
+                for k in range(self.lib.mhip_kernel_count())}
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
             self.lib.mhip_craft_destroy(self.h)

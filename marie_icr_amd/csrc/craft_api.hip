@@ -289,6 +289,23 @@ extern "C" size_t mhip_craft_workspace_bytes(mhip_craft* m, int h, int w, int ca
   return p.total;
 }
 
+extern "C" double mhip_craft_kernel_flops(mhip_craft* m, int kid, int h, int w, int canvas_size, double mag_ratio) {
+  CPlan p;
+  if (!m || make_cplan(m, h, w, canvas_size, mag_ratio, &p)) return 0.0;
+  const double px1 = (double)p.H * p.W;
+  // resolution divisor (pixels = px1 / div) of every layer of kL, in table order
+  static const int div[NL] = {1, 1, 4, 4, 16, 16, 16, 64, 64, 64, 256, 256, 256, 256, 256, 256, 64, 64, 16, 16, 4, 4,
+                              4, 4, 4, 4, 4};
+  double first = 0.0, rest = 0.0;
+  for (int i = 0; i < NL; ++i) {
+    const double f = 2.0 * (px1 / div[i]) * kL[i].co * kL[i].ci * kL[i].k * kL[i].k;
+    if (i == 0) first = f; else rest += f;
+  }
+  if (kid == MHIP_K_CONV_FIRST) return first;
+  if (kid == MHIP_K_CONV_IGEMM) return rest;
+  return 0.0;
+}
+
 // Network forward: page uint8 [h][w][3] (device) -> scores fp32 [H32/2][W32/2][2] (device).
 extern "C" int mhip_craft_forward(mhip_craft* m, const uint8_t* page_dev, int h, int w, int canvas_size,
                                   double mag_ratio, float* scores_dev) {

@@ -169,6 +169,16 @@ def make_craft_state(seed: int = 0, score_gain: float = 4.0) -> Dict[str, np.nda
     return st
 
 
+def page_line_boxes(h: int, w: int, n_lines: int = 0) -> np.ndarray:
+    """Ground-truth text-line boxes (n_lines, 4) int32 x, y, w, h of ``make_page_bgr``'s layout."""
+    if n_lines <= 0:
+        n_lines = max(1, h // 80)
+    pitch = h // (n_lines + 1)
+    gh = max(6, int(pitch * 0.5))
+    x0 = w // 16
+    return np.array([[x0, pitch * (li + 1) - gh // 2, w - 2 * x0, gh] for li in range(n_lines)], np.int32)
+
+
 def make_page_bgr(seed: int, h: int, w: int, n_lines: int = 0) -> np.ndarray:
     """Seeded synthetic page, uint8 HxWx3 (BGR like OpenCV): white paper, dark word-like blocks laid out
     on text lines, mild noise.  Deterministic across platforms (PCG64 + integer arithmetic only)."""
