@@ -37,25 +37,29 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 256, ROWB = 128, NTHREADS = 512;
-constexpr int A_BYTES = BM * ROWB;  // 32 KiB
+constexpr int ROWB = 128, NTHREADS = 512;
 
-// Two tile shapes share one kernel body:
-//   BN = 128: waves 4(M) x 2(N),  64x64 per wave, 3-slot ring of 48 KiB  (N <= 128)
-//   BN = 256: waves 2(M) x 4(N), 128x64 per wave, 2-slot ring of 64 KiB  (N  > 128): 1.5x fewer L2->LDS
+// Three tile shapes share one kernel body (8 waves each; every wave owns 64 output columns):
+//   BN =  64, BM = 512: waves 8(M) x 1(N),  64x64 per wave, 2-slot ring of 72 KiB  (N <= 64: no half-empty N tile)
+//   BN = 128, BM = 256: waves 4(M) x 2(N),  64x64 per wave, 3-slot ring of 48 KiB  (N <= 128)
+//   BN = 256, BM = 256: waves 2(M) x 4(N), 128x64 per wave, 2-slot ring of 64 KiB  (N  > 128): 1.5x fewer L2->LDS
 //             bytes and 25 % fewer LDS fragment reads per MFMA than the 128-wide tile.
 template <int BN_>
 struct Cfg {
   static constexpr int BN = BN_;
+  static constexpr int BM = (BN_ == 64) ? 512 : 256;
   static constexpr int WN = BN_ / 64;            // waves along N
   static constexpr int WM = 8 / WN;              // waves along M
   static constexpr int MT = BM / WM / 16;        // 16-row MFMA tiles per wave along M (4 or 8)
   static constexpr int NSTAGE = (BN_ == 128) ? 3 : 2;
+  static constexpr int A_BYTES = BM * ROWB;
   static constexpr int B_BYTES = BN_ * ROWB;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int ACHUNKS = BM / 64;        // A chunks staged per thread per slice
   static constexpr int WCHUNKS = BN_ / 64;       // W chunks staged per thread per slice
-  static constexpr int GL = 4 + WCHUNKS;         // LDS-DMA instructions per wave per slice
-  static constexpr int EPI_BYTES = BM * (128 * 4 + 16);  // one 128-column epilogue pass, fp32 worst case
+  static constexpr int GL = ACHUNKS + WCHUNKS;   // LDS-DMA instructions per wave per slice
+  static constexpr int EPW = BN_ < 128 ? BN_ : 128;       // output columns per epilogue pass
+  static constexpr int EPI_BYTES = BM * (EPW * 4 + 16);   // one epilogue pass, fp32 worst case
   static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
   static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 };
@@ -147,6 +151,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   constexpr int E = Tr<T>::E;            // elements per 16-B chunk
   constexpr int BKE = ROWB / sizeof(T);  // elements per K slice
   constexpr int MT = C::MT;
+  constexpr int BM = C::BM;
+  constexpr int A_BYTES = C::A_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -161,14 +167,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   }
   const int m0 = mt * BM, n0 = nt * C::BN;
 
-  // ---- staging set-up: each thread moves 4 A chunks + BN/64 W chunks per slice -----------
+  // ---- staging set-up: each thread moves BM/64 A chunks + BN/64 W chunks per slice ---------
   const int srow = wave * 8 + (lane >> 3);             // row within a 64-row group
   const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);   // logical chunk this lane fetches
-  const char* a_src[4];
-  int a_y[4], a_x[4];
+  const char* a_src[C::ACHUNKS];
+  int a_y[C::ACHUNKS], a_x[C::ACHUNKS];
   const char* w_src[C::WCHUNKS];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < C::ACHUNKS; ++q) {
     int m = m0 + q * 64 + srow;
     int b = 0, y = -100000, x = -100000;  // invalid rows fail every bounds test
     if (m < p.M) decode_row<POOL>(p, m, b, y, x);
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     const size_t dstride = (size_t)(first ? p.Cin1 : p.Cin - p.Cin1) * sizeof(T);
     const size_t dcol = (size_t)(first ? c0 : c0 - p.Cin1) * sizeof(T);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < C::ACHUNKS; ++q) {
       int yy = a_y[q] + dy - p.pad, xx = a_x[q] + dx - p.pad;
       bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
       const char* src;
@@ -242,8 +248,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   int slot = 0, fill = D % C::NSTAGE;
   for (int it = 0; it < p.nslices; ++it) {
     if (D > 1 && it + 1 < p.nslices) {
-      if (C::GL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      static_assert(D == 1 || C::GL == 6, "counted vmcnt below assumes 6 LDS-DMA instructions per slice");
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -285,16 +291,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   const int Mq = p.M / PF;
   const int q0 = m0 / PF;
   const int oe = p.out_f32 ? 4 : (int)sizeof(T);
-  const int pitch = 128 * oe + 16;
+  constexpr int EPW = C::EPW;
+  const int pitch = EPW * oe + 16;
   const size_t grow = (size_t)p.N * oe;  // global bytes per output pixel
 #pragma unroll
-  for (int pass = 0; pass < C::BN / 128; ++pass) {
+  for (int pass = 0; pass < C::BN / EPW; ++pass) {
     __syncthreads();  // ring (or previous pass) fully consumed
     if ((wc >> 1) == pass) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int lc = (wc & 1) * 64 + j * 16 + frow;
-        const int n = n0 + pass * 128 + lc;
+        const int n = n0 + pass * EPW + lc;
         const float sc = (p.scale && n < p.N) ? p.scale[n] : 1.f;
         const float bi = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
@@ -328,9 +335,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       }
     }
     __syncthreads();
-    const int nbase = n0 + pass * 128;
+    const int nbase = n0 + pass * EPW;
     if ((grow & 15) == 0) {
-      const int cpr = 128 * oe / 16;       // 16-B chunks per staged row
+      const int cpr = EPW * oe / 16;       // 16-B chunks per staged row
       const int epc = 16 / oe;             // elements per chunk
       for (int c = tid; c < RQ * cpr; c += NTHREADS) {
         const int row = c / cpr, ch = c - row * cpr;
@@ -341,8 +348,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
         }
       }
     } else {  // ragged N (e.g. the 95-class prediction layer): element-wise
-      for (int e = tid; e < RQ * 128; e += NTHREADS) {
-        const int row = e >> 7, col = e & 127;
+      for (int e = tid; e < RQ * EPW; e += NTHREADS) {
+        const int row = e / EPW, col = e - row * EPW;
         const int q = q0 + row, n = nbase + col;
         if (q < Mq && n < p.N) {
           if (oe == 4) *(float*)(p.out + (size_t)q * grow + (size_t)n * 4) = *(const float*)(smem + row * pitch + col * 4);
@@ -437,7 +444,7 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   } else {
     M = (long long)d.B * a.Ho * a.Wo;
   }
-  if (M <= 0 || M > 0x7fffffffLL - BM) return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: M=%lld out of range", M);
+  if (M <= 0 || M > 0x7fffffffLL - 512) return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: M=%lld out of range", M);
   a.M = (int)M;
   a.N = d.N;
   a.Ktot = d.KH * d.KW * d.Cin;
@@ -445,10 +452,13 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.nslices = d.KH * d.KW * a.cpt;
   a.relu = d.relu;
   a.out_f32 = d.out_f32;
-  const int bn = (a.N > 128) ? 256 : 128;
-  a.mtiles = (a.M + BM - 1) / BM;
+  const int bn = (a.N > 128) ? 256 : (a.N > 64 ? 128 : 64);
+  const int bm = (bn == 64) ? 512 : 256;
+  a.mtiles = (a.M + bm - 1) / bm;
   a.ntiles = (a.N + bn - 1) / bn;
   if (precision == MHIP_PREC_F16)
-    return bn == 256 ? launch_t<_Float16, 256>(ctx, a, d.pool) : launch_t<_Float16, 128>(ctx, a, d.pool);
-  return bn == 256 ? launch_t<float, 256>(ctx, a, d.pool) : launch_t<float, 128>(ctx, a, d.pool);
+    return bn == 256 ? launch_t<_Float16, 256>(ctx, a, d.pool)
+                     : (bn == 128 ? launch_t<_Float16, 128>(ctx, a, d.pool) : launch_t<_Float16, 64>(ctx, a, d.pool));
+  return bn == 256 ? launch_t<float, 256>(ctx, a, d.pool)
+                   : (bn == 128 ? launch_t<float, 128>(ctx, a, d.pool) : launch_t<float, 64>(ctx, a, d.pool));
 }

@@ -81,3 +81,34 @@ def test_conv_rejects_bad_cin(ctx):
     with pytest.raises(MarieHipError):
         ctx.conv2d_nhwc(PREC_F16, ConvDesc(1, 4, 4, 48, 3, 3, 1, 64, 0, 0, 0, 1, 0), x.data_ptr(), w.data_ptr(), 0, 0,
                         o.data_ptr())
+
+
+def test_conv_dilated_and_concat_inputs(ctx):
+    """3x3 dilation-6 conv (CRAFT fc6) and the concat-free 1x1 conv over two tensors (CRAFT U-net)."""
+    from marie_icr_amd._lib import PREC_F32, ConvDesc
+
+    g = torch.Generator().manual_seed(7)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # dilated
+    x = torch.rand((1, 20, 23, 64), generator=g) * 2 - 1
+    w = (torch.rand((96, 3, 3, 64), generator=g) * 2 - 1) * 0.07
+    b = torch.rand((96,), generator=g) - 0.5
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, padding=6, dilation=6).permute(0, 2, 3, 1)
+    out = torch.full(ref.shape, float("nan"), device="cuda")
+    dx, dw, db = x.cuda(), w.cuda(), b.cuda()        # keep the device tensors alive across the launch
+    ctx.conv2d_nhwc(PREC_F32, ConvDesc(1, 20, 23, 64, 3, 3, 6, 96, 0, 0, 0, 6, 0), dx.data_ptr(), dw.data_ptr(), 0,
+                    db.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # concat of two inputs (64 + 128 channels) -> 1x1
+    a = torch.rand((2, 9, 11, 64), generator=g) * 2 - 1
+    c = torch.rand((2, 9, 11, 128), generator=g) * 2 - 1
+    w = (torch.rand((64, 1, 1, 192), generator=g) * 2 - 1) * 0.1
+    cat = torch.cat([a, c], dim=3)
+    ref = F.relu(F.conv2d(cat.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b[:64])).permute(0, 2, 3, 1)
+    out = torch.full(ref.shape, float("nan"), device="cuda")
+    da, dc, dw, db = a.cuda(), c.cuda(), w.cuda(), b[:64].cuda()
+    ctx.conv2d_nhwc(PREC_F32, ConvDesc(2, 9, 11, 192, 1, 1, 0, 64, 0, 1, 0, 1, 64), da.data_ptr(), dw.data_ptr(), 0,
+                    db.data_ptr(), out.data_ptr(), in2_ptr=dc.data_ptr())
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
