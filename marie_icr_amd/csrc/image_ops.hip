@@ -119,6 +119,76 @@ __global__ __launch_bounds__(256) void conv_rgb_first_kernel(const uint8_t* __re
   }
 }
 
+// f16 mode: the same layer on the matrix cores.  K = 27 is padded to one 32-deep MFMA step
+// (v_mfma_f32_16x16x32_f16).  The FILTERS are the A operand (rows = output channels, constant in registers for the
+// whole kernel) and 16 PIXELS are the B operand, so in the C layout a lane ends up with 4 consecutive channels of one
+// pixel: the 64-channel NHWC line of a pixel is written as 8-byte pieces that tile 2 KiB contiguously per wave.
+// The im2col row of a pixel is 3 runs of 9 contiguous bytes (k = dy*9 + dx*3 + c), gathered per lane straight from
+// the uint8 image; the kernel is bound by the 650 MB/page activation write, not by arithmetic.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void conv_rgb_first_mfma_kernel(const uint8_t* __restrict__ img, int th, int tw,
+                                                                  int H, int W, const float* __restrict__ w27x64,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ bias,
+                                                                  _Float16* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int frow = lane & 15, fg = lane >> 4;
+  // A fragments: filter bank rows (channels) t*16 + frow, k = 8*fg + j  (zero for k >= 27)
+  half8 wf[4];
+  float sc[4][4], bi[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * fg + j;
+      wf[t][j] = (k < 27) ? (_Float16)w27x64[k * 64 + t * 16 + frow] : (_Float16)0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // C rows of this lane: channels t*16 + fg*4 + r
+      sc[t][r] = scale[t * 16 + fg * 4 + r];
+      bi[t][r] = bias[t * 16 + fg * 4 + r];
+    }
+  }
+  const long long npix = (long long)H * W;
+  const long long ntiles = (npix + 15) / 16;
+  const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long tile = wave_id; tile < ntiles; tile += nwaves) {
+    const long long pp = tile * 16 + frow;        // this lane's pixel (B column)
+    const int x = (int)(pp % W), y = (int)(pp / W);
+    half8 bf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * fg + j;                   // k = dy*9 + dx*3 + c
+      const int dy = k / 9, rem = k - dy * 9, dx = rem / 3, c = rem - dx * 3;
+      float v = 0.f;
+      if (k < 27 && pp < npix) {
+        const int yy = y + dy - 1, xx = x + dx - 1;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+          const float u = (yy < th && xx < tw) ? (float)img[((size_t)yy * tw + xx) * 3 + c] : 0.f;
+          v = (u - 127.5f) / 127.5f;
+        }
+      }
+      bf[j] = (_Float16)v;
+    }
+    float4v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], bf, (float4v){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    if (pp < npix) {
+      _Float16* dst = out + (size_t)pp * 64 + fg * 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        half4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (_Float16)fmaxf(acc[t][r] * sc[t][r] + bi[t][r], 0.f);
+        *(half4*)(dst + t * 16) = o;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ max pooling
 template <typename T>
 __device__ __forceinline__ typename Vec<T>::type vmax(typename Vec<T>::type a, typename Vec<T>::type b) {
@@ -250,9 +320,11 @@ int mhip_launch_conv_rgb_first(mhip_ctx* ctx, int precision, const uint8_t* img,
   if (th < 1 || tw < 1 || H < th || W < tw) return mhip_fail(ctx, MHIP_EINVAL, "conv_rgb_first: bad shape");
   unsigned grid = (unsigned)(((long long)H * W + 63) / 64);
   if (precision == MHIP_PREC_F16) {
+    const long long tiles = ((long long)H * W + 15) / 16;
+    const unsigned g2 = (unsigned)std::min<long long>((tiles + 3) / 4, 256 * 16);
     PROF_LAUNCH(ctx, MHIP_K_CONV_FIRST,
-                hipLaunchKernelGGL((conv_rgb_first_kernel<_Float16>), dim3(grid), dim3(256), 0, ctx->stream, img, th,
-                                   tw, H, W, w27x64, scale, bias, (_Float16*)out));
+                hipLaunchKernelGGL(conv_rgb_first_mfma_kernel, dim3(g2), dim3(256), 0, ctx->stream, img, th, tw, H, W,
+                                   w27x64, scale, bias, (_Float16*)out));
   } else {
     PROF_LAUNCH(ctx, MHIP_K_CONV_FIRST,
                 hipLaunchKernelGGL((conv_rgb_first_kernel<float>), dim3(grid), dim3(256), 0, ctx->stream, img, th, tw,
