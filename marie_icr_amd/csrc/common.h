@@ -115,6 +115,8 @@ int mhip_launch_resize_linear_u8(mhip_ctx* ctx, const uint8_t* src, int sh, int 
 int mhip_launch_conv_rgb_first(mhip_ctx* ctx, int precision, const uint8_t* img, int th, int tw, int H, int W,
                                const float* w27x64, const float* scale, const float* bias, void* out);
 int mhip_launch_maxpool(mhip_ctx* ctx, int precision, int k, const void* in, void* out, int B, int H, int W, int C);
+int mhip_launch_score_head(mhip_ctx* ctx, int precision, const void* in, int in_stride, const float* w1,
+                           const float* b1, const float* w2, const float* b2, float* scores, long long npix);
 int mhip_launch_upsample_bilinear(mhip_ctx* ctx, int precision, const void* in, void* out, int B, int Hi, int Wi,
                                   int C, int Ho, int Wo);
 

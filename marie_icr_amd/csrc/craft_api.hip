@@ -65,6 +65,7 @@ struct mhip_craft {
   int precision = MHIP_PREC_F16;
   std::map<std::string, HostTensor> tensors;
   size_t w_off[NL] = {0}, s_off[NL] = {0}, b_off[NL] = {0};
+  size_t head_off = 0;   // fp32 [w1 16x16][b1 16][w2 2x16][b2 2] of conv_cls.6 / conv_cls.8 for the fused score head
   size_t arena_bytes = 0;
   char* arena = nullptr;
   bool ready = false;
@@ -88,6 +89,8 @@ void craft_layout(mhip_craft* m) {
     m->b_off[i] = o;
     o = al256(o + (size_t)std::max(L.coutp, 64) * 4);
   }
+  m->head_off = o;
+  o = al256(o + (256 + 16 + 32 + 2) * 4);
   m->arena_bytes = o;
 }
 
@@ -217,6 +220,24 @@ extern "C" int mhip_craft_finalize(mhip_craft* m) {
       }
     }
   }
+  {
+    const HostTensor* w1 = cfind(m, "conv_cls.6.weight", {16, 16, 1, 1});
+    const HostTensor* b1 = cfind(m, "conv_cls.6.bias", {16});
+    const HostTensor* w2 = cfind(m, "conv_cls.8.weight", {2, 16, 1, 1});
+    const HostTensor* b2 = cfind(m, "conv_cls.8.bias", {2});
+    if (!w1 || !b1 || !w2 || !b2) return MHIP_ESTATE;
+    float* hd = (float*)(h + m->head_off);
+    for (int i = 0; i < 256; ++i) {
+      float v = w1->data[i];
+      hd[i] = m->precision == MHIP_PREC_F16 ? (float)(_Float16)v : v;   // same rounding as the MFMA path's weights
+    }
+    memcpy(hd + 256, b1->data.data(), 16 * 4);
+    for (int i = 0; i < 32; ++i) {
+      float v = w2->data[i];
+      hd[272 + i] = m->precision == MHIP_PREC_F16 ? (float)(_Float16)v : v;
+    }
+    memcpy(hd + 304, b2->data.data(), 2 * 4);
+  }
   int rc = mhip_craft_alloc_arena(m);
   if (rc) return rc;
   m->ready = false;
@@ -299,7 +320,8 @@ extern "C" double mhip_craft_kernel_flops(mhip_craft* m, int kid, int h, int w, 
   double first = 0.0, rest = 0.0;
   for (int i = 0; i < NL; ++i) {
     const double f = 2.0 * (px1 / div[i]) * kL[i].co * kL[i].ci * kL[i].k * kL[i].k;
-    if (i == 0) first = f; else rest += f;
+    if (i == 0) first = f;
+    else if (i < 25) rest += f;   // conv_cls.6 / .8 run in the fused score-head kernel, not on conv_igemm
   }
   if (kid == MHIP_K_CONV_FIRST) return first;
   if (kid == MHIP_K_CONV_IGEMM) return rest;
@@ -400,8 +422,11 @@ extern "C" int mhip_craft_forward(mhip_craft* m, const uint8_t* page_dev, int h,
   CK(conv(22, act(U4B), H2, W2, act(C0), POOL_NONE, 1));
   CK(conv(23, act(C0), H2, W2, act(C1), POOL_NONE, 1));
   CK(conv(24, act(C1), H2, W2, act(C2), POOL_NONE, 1));
-  CK(conv(25, act(C2), H2, W2, act(C3), POOL_NONE, 1));
-  CK(conv(26, act(C3), H2, W2, scores_dev, POOL_NONE, 0, 1, 0, nullptr, 0, 1));
+  {
+    const float* hd = (const float*)(A + m->head_off);   // conv_cls.6 + ReLU + conv_cls.8 fused per pixel
+    CK(mhip_launch_score_head(ctx, prec, act(C2), 64, hd, hd + 256, hd + 272, hd + 304, scores_dev,
+                              (long long)H2 * W2));
+  }
 #undef CK
   return MHIP_OK;
 }

@@ -189,6 +189,49 @@ __global__ __launch_bounds__(256) void conv_rgb_first_mfma_kernel(const uint8_t*
   }
 }
 
+// ------------------------------------------------------------------ detector score head
+// conv_cls[6..8]: ReLU(conv1x1 16->16) then conv1x1 16->2 (marie/models/craft/craft.py:46-49), fused per pixel.
+// 288 MACs per pixel are nothing; the layer is the read of 16 real channels (stored in a 64-channel padded NHWC
+// line) and the write of two fp32 scores.  Keeping it off the 128-wide MFMA tile saves two launches that ran at
+// < 2 % tile occupancy.  Weights: w1 [16][16], b1 [16], w2 [2][16], b2 [2] fp32 in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void score_head_kernel(const T* __restrict__ in, int in_stride,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         float* __restrict__ scores, long long npix) {
+  __shared__ float s1[16 * 16 + 16 + 2 * 16 + 2];
+  for (int i = threadIdx.x; i < 256; i += 256) s1[i] = w1[i];
+  if (threadIdx.x < 16) s1[256 + threadIdx.x] = b1[threadIdx.x];
+  if (threadIdx.x < 32) s1[272 + threadIdx.x] = w2[threadIdx.x];
+  if (threadIdx.x < 2) s1[304 + threadIdx.x] = b2[threadIdx.x];
+  __syncthreads();
+  typedef typename Vec<T>::type V;
+  constexpr int N = Vec<T>::N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+       i += (long long)gridDim.x * blockDim.x) {
+    float x[16];
+    const T* p = in + (size_t)i * in_stride;
+#pragma unroll
+    for (int q = 0; q < 16 / N; ++q) {
+      const V v = *(const V*)(p + q * N);
+#pragma unroll
+      for (int k = 0; k < N; ++k) x[q * N + k] = (float)v[k];
+    }
+    float o0 = s1[304], o1 = s1[305];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float h = s1[256 + j];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) h = fmaf(x[k], s1[j * 16 + k], h);
+      h = fmaxf(h, 0.f);
+      if (sizeof(T) == 2) h = (float)(_Float16)h;   // the unfused f16 path rounds this activation to f16
+      o0 = fmaf(h, s1[272 + j], o0);
+      o1 = fmaf(h, s1[288 + j], o1);
+    }
+    ((float2*)scores)[i] = make_float2(o0, o1);
+  }
+}
+
 // ------------------------------------------------------------------ max pooling
 template <typename T>
 __device__ __forceinline__ typename Vec<T>::type vmax(typename Vec<T>::type a, typename Vec<T>::type b) {
@@ -375,5 +418,23 @@ int mhip_launch_upsample_bilinear(mhip_ctx* ctx, int precision, const void* in, 
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "upsample launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int mhip_launch_score_head(mhip_ctx* ctx, int precision, const void* in, int in_stride, const float* w1,
+                           const float* b1, const float* w2, const float* b2, float* scores, long long npix) {
+  if (npix < 1 || in_stride < 16) return mhip_fail(ctx, MHIP_EINVAL, "score_head: bad shape");
+  const unsigned grid = grid_for(npix);
+  if (precision == MHIP_PREC_F16) {
+    PROF_LAUNCH(ctx, MHIP_K_IMAGE_OPS,
+                hipLaunchKernelGGL((score_head_kernel<_Float16>), dim3(grid), dim3(256), 0, ctx->stream,
+                                   (const _Float16*)in, in_stride, w1, b1, w2, b2, scores, npix));
+  } else {
+    PROF_LAUNCH(ctx, MHIP_K_IMAGE_OPS,
+                hipLaunchKernelGGL((score_head_kernel<float>), dim3(grid), dim3(256), 0, ctx->stream, (const float*)in,
+                                   in_stride, w1, b1, w2, b2, scores, npix));
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "score_head launch: %s", hipGetErrorString(e));
   return 0;
 }
