@@ -119,9 +119,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["pages", "crnn"], default="pages")
-    ap.add_argument("--pages", type=int, default=8, help="pages per GPU per step (workload pages)")
+    ap.add_argument("--pages", type=int, default=12, help="pages per GPU per step (workload pages)")
     ap.add_argument("--crops", choices=["lines", "detector"], default="lines")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=6,
                     help="page pipelines per GPU (one context + stream + host thread each): the host-side box "
                          "finalisation of one page overlaps the kernels of another")
     ap.add_argument("--lines", type=int, default=1024, help="lines per GPU per step (workload crnn)")
