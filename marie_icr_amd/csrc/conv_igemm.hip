@@ -29,15 +29,11 @@
 //     XCD's L2, and vertically adjacent m-tiles share their halo rows.
 //   * f16 operands use v_mfma_f32_16x16x32_f16; the exact-fp32 parity mode uses
 //     v_mfma_f32_16x16x4_f32 on the same LDS image (k order permuted identically for A and W).
-#include "common.h"
+#include "igemm_common.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float float4v __attribute__((ext_vector_type(4)));
-typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+using namespace igemm;
 
 namespace {
-
-constexpr int ROWB = 128, NTHREADS = 512;
 
 // Three tile shapes share one kernel body (8 waves each; every wave owns 64 output columns):
 //   BN =  64, BM = 512: waves 8(M) x 1(N),  64x64 per wave, 2-slot ring of 72 KiB  (N <= 64: no half-empty N tile)
@@ -51,67 +47,28 @@ struct Cfg {
   static constexpr int WN = BN_ / 64;            // waves along N
   static constexpr int WM = 8 / WN;              // waves along M
   static constexpr int MT = BM / WM / 16;        // 16-row MFMA tiles per wave along M (4 or 8)
-  static constexpr int NSTAGE = (BN_ == 128) ? 3 : 2;
-  static constexpr int A_BYTES = BM * ROWB;
-  static constexpr int B_BYTES = BN_ * ROWB;
+#ifdef IGEMM_KSPLIT
+  // Explored variant (N tile 256): each K slice staged as two 64-byte half-rows (k-groups) in a 4-slot ring of 32 KiB
+  // half-slices, so three half-slices (96 KiB) are in flight and a k-group's MFMAs start as soon as ITS half has
+  // landed.  Measured 8-10 % SLOWER than the 2-slot whole-slice ring (twice the barriers; profiles/r01/h_*): off.
+  static constexpr bool KSPLIT = (BN_ == 256);
+#else
+  static constexpr bool KSPLIT = false;
+#endif
+  static constexpr int NSTAGE = KSPLIT ? 4 : ((BN_ == 128) ? 3 : 2);
+  static constexpr int HROWB = KSPLIT ? 64 : ROWB;        // bytes of one staged row
+  static constexpr int A_BYTES = BM * HROWB;
+  static constexpr int B_BYTES = BN_ * HROWB;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int ACHUNKS = BM / 64;        // A chunks staged per thread per slice
-  static constexpr int WCHUNKS = BN_ / 64;       // W chunks staged per thread per slice
-  static constexpr int GL = ACHUNKS + WCHUNKS;   // LDS-DMA instructions per wave per slice
+  static constexpr int RPI = 64 * 16 / HROWB / 1;         // rows covered by one wave-instruction (8 or 16)
+  static constexpr int ACHUNKS = BM * (HROWB / 16) / NTHREADS;   // A chunks staged per thread per (half-)slice
+  static constexpr int WCHUNKS = BN_ * (HROWB / 16) / NTHREADS;  // W chunks
+  static constexpr int GL = ACHUNKS + WCHUNKS;   // LDS-DMA instructions per wave per (half-)slice
   static constexpr int EPW = BN_ < 128 ? BN_ : 128;       // output columns per epilogue pass
   static constexpr int EPI_BYTES = BM * (EPW * 4 + 16);   // one epilogue pass, fp32 worst case
   static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
   static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 };
-
-struct IgemmArgs {
-  const char* in;
-  const char* w;
-  const float* scale;
-  const float* bias;
-  char* out;
-  const char* zeros;
-  int B, H, W, Cin;
-  int KH, KW, pad;
-  int Ho, Wo, Hp, Wp;
-  int N, M;      // M = rows in pool-friendly order (pre-pool)
-  int Ktot;      // KH*KW*Cin
-  int nslices;   // Ktot / (ROWB/sizeof(T))
-  int cpt;       // slices per tap
-  int relu, out_f32;
-  int mtiles, ntiles;
-  int dil;             // filter dilation (1 = dense)
-  const char* in2;     // second input of a channel-concatenated 1x1 conv (DUAL kernels only)
-  int Cin1;            // channels taken from `in`; the remaining Cin - Cin1 come from `in2`
-};
-
-template <typename T>
-struct Tr;
-template <>
-struct Tr<_Float16> {
-  static constexpr int E = 8;
-  typedef half8 chunk_t;
-  static __device__ __forceinline__ void mma(const chunk_t& a, const chunk_t& b, float4v& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-  }
-};
-template <>
-struct Tr<float> {
-  static constexpr int E = 4;
-  typedef float4v chunk_t;
-  static __device__ __forceinline__ void mma(const chunk_t& a, const chunk_t& b, float4v& c) {
-    // lane group g = lane>>4 holds k = 4g+j in element j; MFMA j contracts k = {j, 4+j, 8+j, 12+j}
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
-  }
-};
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 template <int POOL>
 __device__ __forceinline__ void decode_row(const IgemmArgs& p, int m, int& b, int& y, int& x) {
@@ -136,11 +93,6 @@ __device__ __forceinline__ void decode_row(const IgemmArgs& p, int m, int& b, in
     b = r / p.Hp;
     y = 2 * yp + sub;
   }
-}
-
-template <typename OT>
-__device__ __forceinline__ void lds_put(char* base, int pitch, int row, int col, float v) {
-  *(OT*)(base + row * pitch + col * (int)sizeof(OT)) = (OT)v;
 }
 
 template <typename T, int POOL, int BN_, bool DUAL>
@@ -168,14 +120,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   const int m0 = mt * BM, n0 = nt * C::BN;
 
   // ---- staging set-up: each thread moves BM/64 A chunks + BN/64 W chunks per slice ---------
-  const int srow = wave * 8 + (lane >> 3);             // row within a 64-row group
-  const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);   // logical chunk this lane fetches
+  // a wave-instruction covers RPI rows; a thread's q-th chunk sits RPI*8 rows further down
+  constexpr int RPI = C::RPI, RSTEP = RPI * 8;
+  const int srow = wave * RPI + (C::KSPLIT ? (lane >> 2) : (lane >> 3));   // row within a RSTEP-row group
+  const int lchunk = C::KSPLIT ? ((lane & 3) ^ ((srow >> 1) & 3))          // logical chunk this lane fetches
+                               : ((lane & 7) ^ ((srow >> 1) & 7));
   const char* a_src[C::ACHUNKS];
   int a_y[C::ACHUNKS], a_x[C::ACHUNKS];
   const char* w_src[C::WCHUNKS];
 #pragma unroll
   for (int q = 0; q < C::ACHUNKS; ++q) {
-    int m = m0 + q * 64 + srow;
+    int m = m0 + q * RSTEP + srow;
     int b = 0, y = -100000, x = -100000;  // invalid rows fail every bounds test
     if (m < p.M) decode_row<POOL>(p, m, b, y, x);
     a_y[q] = y;
@@ -186,19 +141,21 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   }
 #pragma unroll
   for (int q = 0; q < C::WCHUNKS; ++q) {
-    int n = n0 + q * 64 + srow;
+    int n = n0 + q * RSTEP + srow;
     w_src[q] = (n < p.N) ? p.w + ((size_t)n * p.Ktot + (size_t)lchunk * E) * sizeof(T) : nullptr;
   }
 
-  auto stage = [&](int it, int slot) {
+  auto stage = [&](int hs, int slot) {
+    const int it = C::KSPLIT ? (hs >> 1) : hs;            // K slice
+    const int hoff = C::KSPLIT ? (hs & 1) * 64 : 0;       // byte offset of the k-group half inside the slice
     int tap = it / p.cpt, cc = it - tap * p.cpt;
     int dy = (tap / p.KW) * p.dil, dx = (tap - (tap / p.KW) * p.KW) * p.dil;
-    size_t a_off = (((size_t)dy * p.W + dx) * p.Cin + (size_t)cc * BKE) * sizeof(T);
-    size_t w_off = (size_t)it * BKE * sizeof(T);
-    char* la = smem + slot * C::STAGE_BYTES + wave * 8 * ROWB;
+    size_t a_off = (((size_t)dy * p.W + dx) * p.Cin + (size_t)cc * BKE) * sizeof(T) + hoff;
+    size_t w_off = (size_t)it * BKE * sizeof(T) + hoff;
+    char* la = smem + slot * C::STAGE_BYTES + wave * RPI * C::HROWB;
     char* lb = la + A_BYTES;
     // DUAL (KH = KW = 1, pad = 0): channel slice cc comes from `in` or from `in2`
-    const int c0 = cc * BKE + lchunk * E;
+    const int c0 = cc * BKE + lchunk * E + hoff / (int)sizeof(T);
     const bool first = c0 < p.Cin1;
     const char* dbase = first ? p.in : p.in2;
     const size_t dstride = (size_t)(first ? p.Cin1 : p.Cin - p.Cin1) * sizeof(T);
@@ -210,12 +167,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       const char* src;
       if (DUAL) src = ok ? dbase + (size_t)a_src[q] * dstride + dcol : p.zeros;
       else src = ok ? a_src[q] + a_off : p.zeros;
-      glds16(src, la + q * 64 * ROWB);
+      glds16(src, la + q * RSTEP * C::HROWB);
     }
 #pragma unroll
     for (int q = 0; q < C::WCHUNKS; ++q) {
       const char* src = w_src[q] ? w_src[q] + w_off : p.zeros;
-      glds16(src, lb + q * 64 * ROWB);
+      glds16(src, lb + q * RSTEP * C::HROWB);
     }
   };
 
@@ -228,47 +185,49 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 
   const int wr = wave / C::WN, wc = wave % C::WN;
   const int frow = lane & 15, fg = lane >> 4;
-  // per-lane LDS byte offsets of k-group 0 (k-group 1 = offset ^ 64)
+  // per-lane LDS byte offsets of k-group 0 (k-group 1 = offset ^ 64; KSPLIT: the other half-slice slot)
   int a_off0[MT], b_off0[4];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     int ra = wr * (MT * 16) + t * 16 + frow;
-    a_off0[t] = ra * ROWB + ((fg ^ ((ra >> 1) & 7)) << 4);
+    a_off0[t] = C::KSPLIT ? ra * 64 + ((fg ^ ((ra >> 1) & 3)) << 4) : ra * ROWB + ((fg ^ ((ra >> 1) & 7)) << 4);
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     int rb = wc * 64 + t * 16 + frow;
-    b_off0[t] = A_BYTES + rb * ROWB + ((fg ^ ((rb >> 1) & 7)) << 4);
+    b_off0[t] = A_BYTES + (C::KSPLIT ? rb * 64 + ((fg ^ ((rb >> 1) & 3)) << 4) : rb * ROWB + ((fg ^ ((rb >> 1) & 7)) << 4));
   }
 
-  // ---- main loop: NSTAGE-slot ring, GL LDS-DMA instructions per wave per slice -----------
-  constexpr int D = C::NSTAGE - 1;  // slices in flight ahead of the one being computed
+  // ---- main loop: NSTAGE-slot ring, GL LDS-DMA instructions per wave per (half-)slice -------
+  constexpr int D = C::NSTAGE - 1;  // (half-)slices in flight ahead of the one being computed
+  const int nsteps = C::KSPLIT ? 2 * p.nslices : p.nslices;
   stage(0, 0);
-  if (D > 1 && p.nslices > 1) stage(1, 1);
+  if (D > 1 && nsteps > 1) stage(1, 1);
+  if (D > 2 && nsteps > 2) stage(2, 2);
   int slot = 0, fill = D % C::NSTAGE;
-  for (int it = 0; it < p.nslices; ++it) {
-    if (D > 1 && it + 1 < p.nslices) {
-      static_assert(D == 1 || C::GL == 6, "counted vmcnt below assumes 6 LDS-DMA instructions per slice");
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  for (int it = 0; it < nsteps; ++it) {
+    const int younger = min(D - 1, nsteps - 1 - it);   // (half-)slices issued after the one needed now
+    if (C::GL == 6) {
+      if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (C::GL == 4 && D == 3) {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
+      static_assert(D == 1 || C::GL == 6 || (C::GL == 4 && D == 3), "counted vmcnt table");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-#ifndef IGEMM_STAGE_LATE
-    if (it + D < p.nslices) stage(it + D, fill);
-#endif
+    if (it + D < nsteps) stage(it + D, fill);
     const char* sb = smem + slot * C::STAGE_BYTES;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < (C::KSPLIT ? 1 : 2); ++s) {
       chunk_t a[MT], b[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) b[t] = *(const chunk_t*)(sb + (b_off0[t] ^ (s << 6)));
 #pragma unroll
       for (int t = 0; t < MT; ++t) a[t] = *(const chunk_t*)(sb + (a_off0[t] ^ (s << 6)));
-#ifdef IGEMM_STAGE_LATE
-      // issue the refill of the slot freed at this barrier underneath the first k-group's MFMAs
-      if (s == 0 && it + D < p.nslices) stage(it + D, fill);
-#endif
 #ifndef IGEMM_NO_SETPRIO
       __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster between the barriers (cdna guide T5)
 #endif
@@ -452,6 +411,11 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.nslices = d.KH * d.KW * a.cpt;
   a.relu = d.relu;
   a.out_f32 = d.out_f32;
+  a.PH = a.PW = a.tiles_x = a.tiles_y = 0;
+  {
+    const int r = mhip_try_launch_conv3x3_patch(ctx, precision, d, a);   // 3x3 / pad 1 / dense: patch kernel
+    if (r <= 0) return r;
+  }
   const int bn = (a.N > 128) ? 256 : (a.N > 64 ? 128 : 64);
   const int bm = (bn == 64) ? 512 : 256;
   a.mtiles = (a.M + bm - 1) / bm;
