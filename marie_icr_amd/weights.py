@@ -217,3 +217,118 @@ def make_craft_bench_state() -> Dict[str, np.ndarray]:
     b[1] -= 4.2
     st["conv_cls.8.bias"] = b
     return st
+
+
+# --------------------------------------------------------------------------- #
+# production ICR recognizer: TPS-ResNet-BiLSTM-Attn (marie/document/craft_ocr_processor.py:49-70)
+# --------------------------------------------------------------------------- #
+ICR_IMG_H, ICR_IMG_W, ICR_FIDUCIAL, ICR_MAX_LEN = 32, 100, 20, 48
+
+
+def icr_conv_table():
+    """(conv key, BN key, Cout, Cin, k) of every conv+BN pair of TPS's localization net and of ResNet-45, in
+    state_dict order (reference: marie/models/icr/modules/transformation.py:51-62,
+    marie/models/icr/modules/feature_extraction.py:153-246)."""
+    t = []
+    loc = "Transformation.LocalizationNetwork.conv."
+    for ci, bi, co, cin in ((0, 1, 64, 1), (4, 5, 128, 64), (8, 9, 256, 128), (12, 13, 512, 256)):
+        t.append((f"{loc}{ci}", f"{loc}{bi}", co, cin, 3))
+    r = "FeatureExtraction.ConvNet."
+    t.append((r + "conv0_1", r + "bn0_1", 32, 1, 3))
+    t.append((r + "conv0_2", r + "bn0_2", 64, 32, 3))
+    inpl = 64
+    for li, (planes, blocks) in enumerate(((128, 1), (256, 2), (512, 5), (512, 3)), start=1):
+        for b in range(blocks):
+            p = f"{r}layer{li}.{b}."
+            t.append((p + "conv1", p + "bn1", planes, inpl if b == 0 else planes, 3))
+            t.append((p + "conv2", p + "bn2", planes, planes, 3))
+            if b == 0 and inpl != planes:
+                t.append((p + "downsample.0", p + "downsample.1", planes, inpl, 1))
+        inpl = planes
+        if li < 4:
+            t.append((f"{r}conv{li}", f"{r}bn{li}", planes, planes, 3))
+    t.append((r + "conv4_1", r + "bn4_1", 512, 512, 2))
+    t.append((r + "conv4_2", r + "bn4_2", 512, 512, 2))
+    return t
+
+
+def tps_buffers(F: int = ICR_FIDUCIAL, h: int = ICR_IMG_H, w: int = ICR_IMG_W):
+    """``GridGenerator``'s constant buffers inv_delta_C (F+3, F+3) and P_hat (h*w, F+3) in fp32 —
+    reference: marie/models/icr/modules/transformation.py:103-156 (they are part of the checkpoint)."""
+    cx = np.linspace(-1.0, 1.0, int(F / 2))
+    C = np.concatenate([np.stack([cx, -1 * np.ones(int(F / 2))], axis=1), np.stack([cx, np.ones(int(F / 2))], axis=1)], 0)
+    hat_C = np.zeros((F, F), dtype=float)
+    for i in range(F):
+        for j in range(i, F):
+            r = np.linalg.norm(C[i] - C[j])
+            hat_C[i, j] = hat_C[j, i] = r
+    np.fill_diagonal(hat_C, 1)
+    hat_C = (hat_C ** 2) * np.log(hat_C)
+    delta_C = np.concatenate([np.concatenate([np.ones((F, 1)), C, hat_C], axis=1),
+                              np.concatenate([np.zeros((2, 3)), np.transpose(C)], axis=1),
+                              np.concatenate([np.zeros((1, 3)), np.ones((1, F))], axis=1)], axis=0)
+    inv_delta_C = np.linalg.inv(delta_C)
+    gx = (np.arange(-w, w, 2) + 1.0) / w
+    gy = (np.arange(-h, h, 2) + 1.0) / h
+    P = np.stack(np.meshgrid(gx, gy), axis=2).reshape([-1, 2])
+    n = P.shape[0]
+    P_diff = np.tile(np.expand_dims(P, axis=1), (1, F, 1)) - np.expand_dims(C, axis=0)
+    rbf_norm = np.linalg.norm(P_diff, ord=2, axis=2, keepdims=False)
+    rbf = np.multiply(np.square(rbf_norm), np.log(rbf_norm + 1e-6))
+    P_hat = np.concatenate([np.ones((n, 1)), P, rbf], axis=1)
+    return inv_delta_C.astype(np.float32), P_hat.astype(np.float32)
+
+
+def make_icr_state(seed: int = 0, num_class: int = 96, logit_gain: float = 16.0) -> Dict[str, np.ndarray]:
+    """Seeded TPS-ResNet-BiLSTM-Attn weights with O(1) activations and non-trivial BatchNorm statistics.  The TPS
+    output layer gets small random weights on top of the reference's identity-grid bias so the rectification is a
+    mild, input-dependent warp (exercises grid_sample away from the identity)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 2750159))
+    st: Dict[str, np.ndarray] = {}
+
+    def uni(shape, bound):
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    def bn(prefix, c, gamma=(0.6, 1.4)):
+        st[prefix + ".weight"] = rng.uniform(*gamma, size=(c,)).astype(np.float32)
+        st[prefix + ".bias"] = uni((c,), 0.2)
+        st[prefix + ".running_mean"] = uni((c,), 0.3)
+        st[prefix + ".running_var"] = rng.uniform(0.5, 1.5, size=(c,)).astype(np.float32)
+        st[prefix + ".num_batches_tracked"] = np.asarray(0, dtype=np.int64)
+
+    for ck, bk, co, ci, k in icr_conv_table():
+        st[ck + ".weight"] = uni((co, ci, k, k), np.sqrt(6.0 / (ci * k * k)))
+        # residual branches: damp the second conv of a block so the sum of branches stays O(1)
+        bn(bk, co, gamma=(0.3, 0.7) if bk.endswith("bn2") else (0.6, 1.4))
+    loc = "Transformation.LocalizationNetwork."
+    st[loc + "localization_fc1.0.weight"] = uni((256, 512), np.sqrt(6.0 / 512))
+    st[loc + "localization_fc1.0.bias"] = uni((256,), 0.1)
+    st[loc + "localization_fc2.weight"] = uni((2 * ICR_FIDUCIAL, 256), 0.02)
+    cx = np.linspace(-1.0, 1.0, ICR_FIDUCIAL // 2)
+    top = np.stack([cx, np.linspace(0.0, -1.0, num=ICR_FIDUCIAL // 2)], axis=1)
+    bot = np.stack([cx, np.linspace(1.0, 0.0, num=ICR_FIDUCIAL // 2)], axis=1)
+    st[loc + "localization_fc2.bias"] = np.concatenate([top, bot], axis=0).astype(np.float32).reshape(-1)
+    inv_delta_C, P_hat = tps_buffers()
+    st["Transformation.GridGenerator.inv_delta_C"] = inv_delta_C
+    st["Transformation.GridGenerator.P_hat"] = P_hat
+    for j, in_size in ((0, 512), (1, 256)):
+        p = f"SequenceModeling.{j}."
+        for sfx in ("", "_reverse"):
+            st[p + "rnn.weight_ih_l0" + sfx] = uni((4 * HIDDEN, in_size), np.sqrt(3.0 / in_size))
+            st[p + "rnn.weight_hh_l0" + sfx] = uni((4 * HIDDEN, HIDDEN), np.sqrt(3.0 / HIDDEN))
+            st[p + "rnn.bias_ih_l0" + sfx] = uni((4 * HIDDEN,), 0.1)
+            st[p + "rnn.bias_hh_l0" + sfx] = uni((4 * HIDDEN,), 0.1)
+        st[p + "linear.weight"] = uni((HIDDEN, 2 * HIDDEN), np.sqrt(6.0 / (2 * HIDDEN)))
+        st[p + "linear.bias"] = uni((HIDDEN,), 0.1)
+    a = "Prediction.attention_cell."
+    st[a + "i2h.weight"] = uni((HIDDEN, HIDDEN), np.sqrt(3.0 / HIDDEN))
+    st[a + "h2h.weight"] = uni((HIDDEN, HIDDEN), np.sqrt(3.0 / HIDDEN))
+    st[a + "h2h.bias"] = uni((HIDDEN,), 0.1)
+    st[a + "score.weight"] = uni((1, HIDDEN), 4.0 * np.sqrt(3.0 / HIDDEN))
+    st[a + "rnn.weight_ih"] = uni((4 * HIDDEN, HIDDEN + num_class), np.sqrt(3.0 / HIDDEN))
+    st[a + "rnn.weight_hh"] = uni((4 * HIDDEN, HIDDEN), np.sqrt(3.0 / HIDDEN))
+    st[a + "rnn.bias_ih"] = uni((4 * HIDDEN,), 0.1)
+    st[a + "rnn.bias_hh"] = uni((4 * HIDDEN,), 0.1)
+    st["Prediction.generator.weight"] = uni((num_class, HIDDEN), logit_gain * np.sqrt(3.0 / HIDDEN))
+    st["Prediction.generator.bias"] = uni((num_class,), 0.1)
+    return st

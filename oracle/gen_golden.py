@@ -126,11 +126,59 @@ def gen_craft(out_dir):
               float(y[..., 0].max()), "link range", float(y[..., 1].min()), float(y[..., 1].max()), missing)
 
 
+def gen_icr(out_dir):
+    """Production recognizer TPS-ResNet-BiLSTM-Attn: the reference's unmodified Model(opt) + AttnLabelConverter and
+    the decode/confidence lines of marie/document/craft_ocr_processor.py:244-272."""
+    from marie_icr_amd.weights import make_icr_state
+
+    sys.path.insert(0, REF_ICR)
+    from model import Model
+    from utils import AttnLabelConverter
+
+    opt = _Opt()
+    opt.Transformation, opt.FeatureExtraction, opt.SequenceModeling, opt.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
+    opt.imgH, opt.imgW, opt.num_fiducial = 32, 100, 20
+    opt.input_channel, opt.output_channel, opt.hidden_size, opt.batch_max_length = 1, 512, 256, 48
+    conv = AttnLabelConverter(CRNN_CHARSET)
+    opt.num_class = len(conv.character)
+    for tag, wseed, iseed, n in (("a", 0, 0, 6), ("b", 1, 5, 3)):
+        st = make_icr_state(wseed)
+        m = Model(opt).eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
+        crops = make_crnn_input(iseed, n, 32, 100)
+        x = torch.from_numpy(crops).float().div(255).sub_(0.5).div_(0.5).unsqueeze(1)
+        with torch.no_grad():
+            rect = m.Transformation(x)
+            preds = m(x, torch.zeros(n, 49, dtype=torch.long), is_train=False)
+            _, idx = preds.max(2)
+            strs = conv.decode(idx, torch.IntTensor([48] * n))
+            pmax, _ = F.softmax(preds, dim=2).max(dim=2)
+        texts, confs = [], []
+        for pred, pm in zip(strs, pmax):
+            eos = pred.find("[s]")
+            pred, pm = pred[:eos], pm[:eos]
+            if pm.numel() == 0:            # the reference raises here; recorded as ("", 0)
+                texts.append("")
+                confs.append(0.0)
+            else:
+                texts.append(pred.upper())
+                confs.append(float(pm.cumprod(dim=0)[-1]))
+        np.savez_compressed(
+            os.path.join(out_dir, f"icr_attn_{tag}.npz"),
+            weight_seed=wseed, input_seed=iseed, weight_sha256=state_checksum(st), crops_u8=crops,
+            rectified=rect.numpy(), logits=preds.numpy(), argmax=idx.numpy().astype(np.int32),
+            strings=np.array(texts), confidence=np.array(confs, np.float32))
+        print("icr", tag, tuple(preds.shape), "max|logit|", float(preds.abs().max()), texts[:3], confs[:3])
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     if "--craft-only" in sys.argv:
         gen_craft(out_dir)
+        return
+    if "--icr-only" in sys.argv:
+        gen_icr(out_dir)
         return
 
     # (1) seeded "scaled" weights, 8 crops 32x256 (BASELINE config-2 shape)
@@ -160,6 +208,7 @@ def main():
         crops_u8=crops, logits=logits, argmax=idx, strings=strs, confidence=conf)
     print("default", logits.shape, "max|logit|", np.abs(logits).max(), strs[:2], conf[:2])
     gen_craft(out_dir)
+    gen_icr(out_dir)
 
 
 if __name__ == "__main__":
