@@ -156,6 +156,32 @@ size_t mhip_crnn_workspace_bytes(mhip_crnn* m, int n, int w);
  * bench.py divides by the measured kernel time for the roofline line.                    */
 double mhip_crnn_kernel_flops(mhip_crnn* m, int kernel_id, int n, int w);
 
+/* ---- production ICR recognizer: TPS-ResNet-BiLSTM-Attn ---------------------------------------- */
+typedef struct mhip_icr mhip_icr;
+/* replaces: Model(opt) with Transformation="TPS", FeatureExtraction="ResNet", SequenceModeling="BiLSTM",
+ * Prediction="Attn" as configured by CraftOcrProcessor (marie/document/craft_ocr_processor.py:49-70,103-146): imgH 32,
+ * imgW 100, 20 fiducial points, hidden 256, batch_max_length 48 (49 decode steps), num_class = 94 chars + [GO] + [s].
+ * Keys are the reference state_dict names ("Transformation.LocalizationNetwork.conv.0.weight", ...,
+ * "Transformation.GridGenerator.P_hat", "FeatureExtraction.ConvNet.layer3.4.bn2.running_var", ...,
+ * "Prediction.attention_cell.rnn.weight_ih", "Prediction.generator.bias"; a "module." prefix is ignored).          */
+int mhip_icr_create(mhip_ctx* ctx, int precision, int num_class, mhip_icr** out);
+int mhip_icr_destroy(mhip_icr* m);
+int mhip_icr_set_tensor(mhip_icr* m, const char* key, const float* data_host, const int64_t* shape, int ndim);
+int mhip_icr_finalize(mhip_icr* m);
+int mhip_icr_alloc_arena(mhip_icr* m);
+int mhip_icr_arena(mhip_icr* m, void** arena_dev, size_t* bytes);
+int mhip_icr_steps(void); /* 49 */
+/* replaces: model(image, text_for_pred, is_train=False) (craft_ocr_processor.py:245): TPS rectification
+ * (marie/models/icr/modules/transformation.py:32-42), ResNet-45 (feature_extraction.py:212-246), BiLSTM x2, and the
+ * 49-step greedy attention decoder (prediction.py:47-61,72-83).  crops_dev uint8 [n][32][100] (already resized and
+ * padded, e.g. by mhip_crop_batch with img_w = 100).  Outputs: logits fp32 [n][49][num_class]; argmax int32 [n][49];
+ * pmax fp32 [n][49] = softmax probability of the arg-max (for the confidence product); rectified fp32 [n][32][100] or
+ * NULL.  The [s]-cut / confidence rule (craft_ocr_processor.py:259-271) is the caller's, as in the reference.       */
+int mhip_icr_forward(mhip_icr* m, const uint8_t* crops_dev, int n, float* logits_dev, int32_t* argmax_dev,
+                     float* pmax_dev, float* rectified_dev);
+int mhip_icr_forward_host(mhip_icr* m, const uint8_t* crops_host, int n, float* logits_host, int32_t* argmax_host,
+                          float* pmax_host, float* rectified_host);
+
 /* ---- CRAFT text detector -------------------------------------------------------------------- */
 typedef struct mhip_craft mhip_craft;
 /* replaces: CRAFT() + load_state_dict(copyStateDict(torch.load(...))), marie/boxes/craft_box_processor.py:260-285.

@@ -33,6 +33,15 @@ _SIGNATURES = (
     ("mhip_kernel_count", _i, []),
     ("mhip_kernel_name", C.c_char_p, [_i]),
     ("mhip_conv2d_nhwc", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_icr_create", _i, [_vp, _i, _i, C.POINTER(_vp)]),
+    ("mhip_icr_destroy", _i, [_vp]),
+    ("mhip_icr_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
+    ("mhip_icr_finalize", _i, [_vp]),
+    ("mhip_icr_alloc_arena", _i, [_vp]),
+    ("mhip_icr_arena", _i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    ("mhip_icr_steps", _i, []),
+    ("mhip_icr_forward", _i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("mhip_icr_forward_host", _i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     ("mhip_craft_create", _i, [_vp, _i, C.POINTER(_vp)]),
     ("mhip_craft_destroy", _i, [_vp]),
     ("mhip_craft_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),

@@ -19,7 +19,8 @@ enum MhipKernelId {
   MHIP_K_IMAGE_OPS = 4,   // resize / max-pool / bilinear up-sample (HBM-bound, 16 B per lane)
   MHIP_K_CCL = 5,         // score-map binarise + connected components + per-component statistics
   MHIP_K_CROP_BATCH = 6,  // fragment -> gray -> Pillow-exact bicubic to height 32 -> replicate pad
-  MHIP_K_COUNT = 7
+  MHIP_K_ATTN = 7,        // attention decoder pieces (context, LSTM cell, arg-max)
+  MHIP_K_COUNT = 8
 };
 
 struct ProfSlot {
@@ -81,6 +82,10 @@ struct ConvDesc {
   int pool = POOL_NONE;
   int relu = 0;
   int out_f32 = 0;
+  int sy = 1;                   // vertical stride (horizontal stride is 1)
+  int pad_x = -1;               // horizontal padding; -1 = same as `pad`
+  const void* res = nullptr;    // residual (same shape/type as out), added before the ReLU; unpooled layers only
+  int ldc = 0;                  // output row pitch in elements; 0 = N
   int dil = 1;                  // filter dilation
   const void* in2 = nullptr;    // optional second input: channels [Cin1, Cin) of a 1x1 conv over cat(in, in2)
   int Cin1 = 0;
@@ -143,3 +148,17 @@ int mhip_crop_resized_width(int w, int h, int img_h, int img_w);
 size_t mhip_crop_scratch_bytes(const mhip_crop_desc* descs, int n, int img_h, int img_w);
 int mhip_launch_crop_batch(mhip_ctx* ctx, const uint8_t* base_dev, const mhip_crop_desc* descs, int n, int img_h,
                            int img_w, void* scratch_dev, uint8_t* out_dev);
+
+// ------------------------------------------------------------------ production ICR recognizer ops (icr_ops.hip)
+int mhip_launch_conv_gray_first(mhip_ctx* ctx, int precision, int in_is_u8, const void* img, int B, int H, int W,
+                                int C, const float* w9xC, const float* scale, const float* bias, void* out);
+int mhip_launch_maxpool_s21_p01(mhip_ctx* ctx, int precision, const void* in, void* out, int B, int H, int W, int C);
+int mhip_launch_avgpool_hw(mhip_ctx* ctx, int precision, const void* in, void* out, int B, int HW, int C);
+int mhip_launch_tps_sample(mhip_ctx* ctx, const uint8_t* crops, const float* cprime, const float* inv_delta_c,
+                           const float* p_hat, float* out, int B, int H, int W, int F);
+int mhip_launch_attn_context(mhip_ctx* ctx, int precision, const float* hproj, const float* hp, int ld_hp,
+                             const float* score_w, const void* H, void* ctx_out, int B, int Tn);
+int mhip_launch_attn_cell(mhip_ctx* ctx, int precision, const float* gctx, const float* ghid, int ld_hp,
+                          const float* w_onehot, const int* chars, float* c, void* h, int B);
+int mhip_launch_argmax_rows(mhip_ctx* ctx, const float* logits, int ld, int C, int* idx, int B);
+int mhip_launch_rowmax_softmax(mhip_ctx* ctx, const float* logits, int rows, int C, int* idx, float* pmax);

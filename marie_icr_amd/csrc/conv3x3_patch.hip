@@ -322,7 +322,8 @@ int launch_patch(mhip_ctx* ctx, const IgemmArgs& a, int pool, int pw_shift, int 
 }  // namespace
 
 int mhip_try_launch_conv3x3_patch(mhip_ctx* ctx, int precision, const ConvDesc& d, IgemmArgs& a) {
-  if (d.KH != 3 || d.KW != 3 || d.pad != 1 || a.dil != 1 || d.in2) return 1;
+  if (d.KH != 3 || d.KW != 3 || d.pad != 1 || a.dil != 1 || d.in2 || a.sy != 1 || a.pad_x != 1 || a.res || a.ldc)
+    return 1;
   // Measured (profiles/r01): the LDS-resident patch removes 45-80 % of the LDS-DMA bytes but the loop stays bound by
   // the one-iteration-deep weight prefetch, so it only ties the tap-gather kernel.  Kept selectable for the next
   // round's deeper weight ring; the default path is conv_igemm.

@@ -135,7 +135,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     if (m < p.M) decode_row<POOL>(p, m, b, y, x);
     a_y[q] = y;
     a_x[q] = x;
-    size_t pix = ((size_t)b * p.H + (y - p.pad)) * p.W + (x - p.pad);  // tap (0,0) position (guarded)
+    if (m < p.M) {                       // input coordinates of tap (0,0)
+      y = y * p.sy - p.pad;
+      x = x - p.pad_x;
+      a_y[q] = y;
+      a_x[q] = x;
+    }
+    size_t pix = ((size_t)b * p.H + y) * p.W + x;  // may be out of bounds; every use is guarded
     if (DUAL) a_src[q] = (const char*)pix;  // 1x1 concat conv: keep the pixel index, pick the tensor per slice
     else a_src[q] = p.in + (pix * p.Cin + (size_t)lchunk * E) * sizeof(T);
   }
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     const size_t dcol = (size_t)(first ? c0 : c0 - p.Cin1) * sizeof(T);
 #pragma unroll
     for (int q = 0; q < C::ACHUNKS; ++q) {
-      int yy = a_y[q] + dy - p.pad, xx = a_x[q] + dx - p.pad;
+      int yy = a_y[q] + dy, xx = a_x[q] + dx;
       bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
       const char* src;
       if (DUAL) src = ok ? dbase + (size_t)a_src[q] * dstride + dcol : p.zeros;
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   const int oe = p.out_f32 ? 4 : (int)sizeof(T);
   constexpr int EPW = C::EPW;
   const int pitch = EPW * oe + 16;
-  const size_t grow = (size_t)p.N * oe;  // global bytes per output pixel
+  const size_t grow = (size_t)(p.ldc ? p.ldc : p.N) * oe;  // global bytes per output pixel
 #pragma unroll
   for (int pass = 0; pass < C::BN / EPW; ++pass) {
     __syncthreads();  // ring (or previous pass) fully consumed
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float t = acc[i][j][r] * sc + bi;
-            v[r] = p.relu ? fmaxf(t, 0.f) : t;
+            v[r] = (p.relu && !p.res) ? fmaxf(t, 0.f) : t;   // with a residual the ReLU follows the add (copy-out)
           }
           const int lr4 = wr * (MT * 16) + i * 16 + fg * 4;  // first of this lane's 4 consecutive tile rows
           if (POOL == POOL_2x2) {
@@ -303,6 +309,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
         const int q = q0 + row, n = nbase + ch * epc;
         if (q < Mq && n < p.N) {
           uint4v val = *(const uint4v*)(smem + row * pitch + ch * 16);
+          if (p.res) {   // out = act(conv + residual): residual read with the same 16-byte coalescing as the store
+            uint4v rv = *(const uint4v*)(p.res + (size_t)q * grow + (size_t)n * oe);
+            if (oe == 4) {
+              float4v a = *(float4v*)&val, r4 = *(float4v*)&rv;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { float t = a[k] + r4[k]; a[k] = p.relu ? fmaxf(t, 0.f) : t; }
+              val = *(uint4v*)&a;
+            } else {
+              half8 a = *(half8*)&val, r8 = *(half8*)&rv;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) { float t = (float)a[k] + (float)r8[k]; a[k] = (_Float16)(p.relu ? fmaxf(t, 0.f) : t); }
+              val = *(uint4v*)&a;
+            }
+          }
           *(uint4v*)(p.out + (size_t)q * grow + (size_t)n * oe) = val;
         }
       }
@@ -360,8 +380,8 @@ int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
 }  // namespace
 
 double mhip_conv_flops(const ConvDesc& d) {
-  const int dil = d.dil > 0 ? d.dil : 1;
-  int Ho = d.H + 2 * d.pad - dil * (d.KH - 1), Wo = d.W + 2 * d.pad - dil * (d.KW - 1);
+  const int dil = d.dil > 0 ? d.dil : 1, sy = d.sy > 0 ? d.sy : 1, px = d.pad_x >= 0 ? d.pad_x : d.pad;
+  int Ho = (d.H + 2 * d.pad - dil * (d.KH - 1) - 1) / sy + 1, Wo = d.W + 2 * px - dil * (d.KW - 1);
   return 2.0 * d.B * Ho * Wo * (double)d.N * d.KH * d.KW * d.Cin;
 }
 
@@ -381,8 +401,18 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.B = d.B; a.H = d.H; a.W = d.W; a.Cin = d.Cin;
   a.KH = d.KH; a.KW = d.KW; a.pad = d.pad;
   a.dil = d.dil > 0 ? d.dil : 1;
-  a.Ho = d.H + 2 * d.pad - a.dil * (d.KH - 1);
-  a.Wo = d.W + 2 * d.pad - a.dil * (d.KW - 1);
+  a.sy = d.sy > 0 ? d.sy : 1;
+  a.pad_x = d.pad_x >= 0 ? d.pad_x : d.pad;
+  a.res = (const char*)d.res;
+  a.ldc = d.ldc;
+  a.Ho = (d.H + 2 * d.pad - a.dil * (d.KH - 1) - 1) / a.sy + 1;
+  a.Wo = d.W + 2 * a.pad_x - a.dil * (d.KW - 1);
+  if (a.res && (d.pool != POOL_NONE || d.out_f32))
+    return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: a residual needs an unpooled output of the activation type");
+  if (a.ldc && (a.ldc < d.N || d.pool != POOL_NONE))
+    return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: bad output pitch %d", a.ldc);
+  if ((a.res || a.ldc) && ((size_t)(a.ldc ? a.ldc : d.N) * (d.out_f32 ? 4 : esz)) % 16 != 0)
+    return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: residual / pitched outputs need 16-byte aligned rows");
   a.in2 = (const char*)d.in2;
   a.Cin1 = d.in2 ? d.Cin1 : d.Cin;
   if (d.in2) {

@@ -21,8 +21,8 @@ int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "lstm_rec",  "ctc_decode",
-                                                 "image_ops",  "ccl",        "crop_batch"};
+static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "lstm_rec",   "ctc_decode",
+                                                 "image_ops",  "ccl",        "crop_batch", "attn"};
 
 extern "C" int mhip_kernel_count(void) { return MHIP_K_COUNT; }
 extern "C" const char* mhip_kernel_name(int k) { return (k >= 0 && k < MHIP_K_COUNT) ? kKernelNames[k] : ""; }

@@ -30,6 +30,10 @@ struct IgemmArgs {
   int dil;             // filter dilation (1 = dense)
   const char* in2;     // second input of a channel-concatenated 1x1 conv (DUAL kernels only)
   int Cin1;            // channels taken from `in`; the remaining Cin - Cin1 come from `in2`
+  int sy;              // vertical stride (1 or 2); horizontal stride is always 1
+  int pad_x;           // horizontal padding (vertical padding is `pad`)
+  const char* res;     // optional residual tensor, same shape/type as the output, added before the ReLU
+  int ldc;             // output row pitch in elements (>= N): lets a GEMM write into a slice of a wider tensor
   int PH, PW;          // conv3x3_patch: output patch of one workgroup (PH*PW = 256 pixels)
   int tiles_x, tiles_y;
 };
