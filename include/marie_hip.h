@@ -216,6 +216,20 @@ int mhip_craft_detect_host(mhip_craft* m, const uint8_t* page_host, int h, int w
                            double mag_ratio, float text_threshold, float link_threshold, float low_text,
                            float* boxes_host, int max_boxes, int* n_boxes, float* scores_host, double* ratio_out);
 
+/* ---- word-box / line geometry of the DiT box processor (host, pure functions; no ctx) --------------------------------- */
+/* replaces: merge_boxes, marie/utils/overlap.py:268-330 (find_overlap_horizontal(center_y_overlap=0.5) :106-183,
+ * merge_bboxes_as_block :186-204).  xyxy fp32 [n][4] -> out_xyxy fp32 (capacity n rows), *n_out rows.       */
+int mhip_merge_boxes(const float* xyxy, int n, float* out_xyxy, int* n_out);
+/* replaces: line_merge, marie/boxes/line_processor.py:105-171.  xywh int32 [n][4] -> merged lines sorted by y
+ * (capacity n rows).  Equal-y boxes keep input order (the reference leaves ties to numpy's unstable sort).   */
+int mhip_line_merge(const int32_t* xywh, int n, int32_t* out_xywh, int* n_out);
+/* replaces: find_line_number per box, marie/boxes/line_processor.py:15-44.  out[i] = 1-based line, -1 if no lines. */
+int mhip_find_line_numbers(const int32_t* lines_xywh, int n_lines, const int32_t* boxes_xywh, int n, int32_t* out);
+/* replaces: lines_from_bboxes, marie/boxes/dit/ulim_dit_box_processor.py:201-288 (rectangle mask, horizontal
+ * erode+dilate, 4-connected components with stats, size filter, line_merge) for a height x width page.
+ * Returns MHIP_ENOMEM with *n_out = needed rows when cap is too small.                                       */
+int mhip_lines_from_bboxes(const float* xyxy, int n, int height, int width, int32_t* out_xywh, int cap, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

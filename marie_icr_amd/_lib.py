@@ -58,6 +58,10 @@ _SIGNATURES = (
     ("mhip_craft_detect_host", _i, [_vp, _vp, _i, _i, _i, C.c_double, C.c_float, C.c_float, C.c_float, _vp, _i,
                                     C.POINTER(_i), _vp, C.POINTER(C.c_double)]),
     ("mhip_crop_batch", _i, [_vp, _vp, _vp, _i, _i, _vp]),
+    ("mhip_merge_boxes", _i, [_vp, _i, _vp, C.POINTER(_i)]),
+    ("mhip_line_merge", _i, [_vp, _i, _vp, C.POINTER(_i)]),
+    ("mhip_find_line_numbers", _i, [_vp, _i, _vp, _i, _vp]),
+    ("mhip_lines_from_bboxes", _i, [_vp, _i, _i, _i, _vp, _i, C.POINTER(_i)]),
     ("mhip_crnn_forward_crops", _i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("mhip_crnn_forward_fragments_host", _i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("mhip_crnn_create", _i, [_vp, _i, _i, C.POINTER(_vp)]),

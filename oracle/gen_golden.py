@@ -171,9 +171,94 @@ def gen_icr(out_dir):
         print("icr", tag, tuple(preds.shape), "max|logit|", float(preds.abs().max()), texts[:3], confs[:3])
 
 
+def _load_ref_geometry():
+    """overlap.py (numpy only) and line_processor.py, unmodified, by path.  line_processor's
+    cv2 / PIL / logger imports are only touched when ``enable_visualization`` is set; placeholders satisfy the import."""
+    import importlib.util
+    import logging
+    import types
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    for name in ("cv2", "marie", "marie.logging_core", "marie.logging_core.predefined", "marie.utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["marie.logging_core.predefined"].default_logger = logging.getLogger("ref")
+    ov = load("marie.utils.overlap", "/root/reference/marie/utils/overlap.py")
+    lp = load("ref_line_processor", "/root/reference/marie/boxes/line_processor.py")
+    return ov, lp
+
+
+def geometry_cases():
+    """Seeded word-box layouts: text lines with jitter, split words, skew, two columns, overlaps, single boxes."""
+    cases = []
+    for seed in range(24):
+        rng = np.random.default_rng(100 + seed)
+        n_lines = int(rng.integers(1, 28))
+        skew = float(rng.uniform(-0.01, 0.01)) if seed % 3 == 0 else 0.0
+        two_col = seed % 4 == 1
+        boxes = []
+        y = float(rng.uniform(40, 200))
+        for _ in range(n_lines):
+            hgt = float(rng.uniform(24, 60))
+            for x0, x_end in (((100.0, 1150.0), (1350.0, 2400.0)) if two_col else ((120.0, 2400.0),)):
+                x = x0 + float(rng.uniform(0, 80))
+                while x < x_end - 60:
+                    w = float(rng.uniform(30, 320))
+                    gap = float(rng.uniform(-6, 40))
+                    yy = y + skew * x + float(rng.uniform(-0.25, 0.25)) * hgt
+                    hh = hgt * float(rng.uniform(0.7, 1.2))
+                    boxes.append([x, yy, min(x + w, x_end), yy + hh])
+                    x += w + gap
+            y += hgt * float(rng.uniform(1.1, 2.2))
+        b = np.asarray(boxes, np.float32)
+        rng.shuffle(b, axis=0)
+        cases.append(b)
+    return cases
+
+
+def gen_geometry(out_dir):
+    ov, lp = _load_ref_geometry()
+    out = {}
+    for k, b in enumerate(geometry_cases()):
+        merged = np.asarray(ov.merge_boxes([row for row in b], 0.08), np.float32).reshape(-1, 4)
+        # word boxes -> (x, y, w, h) int32 as the box processor hands them on (ulim_dit_box_processor.py:757-763)
+        bi = b.astype(np.int32)
+        xywh = np.stack([bi[:, 0], bi[:, 1], bi[:, 2] - bi[:, 0], bi[:, 3] - bi[:, 1]], 1)
+        img = np.zeros((3300, 2550), np.uint8)
+        lines_platform = np.asarray(lp.line_merge(img, [list(r) for r in xywh]), np.int64).reshape(-1, 4)
+        # The reference sorts by y with numpy's default (unstable, CPU-dispatched) argsort, so boxes with equal y come
+        # out in a platform-dependent order.  Second run of the same reference code with that one numpy call forced
+        # to kind="stable": this is the tie rule our build fixes, and the vector the oracle is held to everywhere.
+        plain = np.argsort
+        np.argsort = lambda a, *args, **kw: plain(a, kind="stable")
+        try:
+            lines = np.asarray(lp.line_merge(img, [list(r) for r in xywh]), np.int64).reshape(-1, 4)
+        finally:
+            np.argsort = plain
+        out[f"lines_platform_{k}"] = lines_platform.astype(np.int32)
+        nums = np.asarray([lp.find_line_number(lines, list(r)) for r in xywh], np.int32)
+        blocks = np.asarray([ov.merge_bboxes_as_block(xywh[: 1 + (j % len(xywh))]) for j in range(0, len(xywh), 7)], np.int64)
+        out[f"boxes_{k}"] = b
+        out[f"merged_{k}"] = merged
+        out[f"lines_{k}"] = lines.astype(np.int32)
+        out[f"linenum_{k}"] = nums
+        out[f"blocks_{k}"] = blocks.astype(np.int32)
+        print("geometry", k, len(b), "->", len(merged), "merged,", len(lines), "lines")
+    out["n_cases"] = np.int32(len(geometry_cases()))
+    np.savez_compressed(os.path.join(out_dir, "geometry.npz"), **out)
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if "--geometry-only" in sys.argv:
+        gen_geometry(out_dir)
+        return
     if "--craft-only" in sys.argv:
         gen_craft(out_dir)
         return
