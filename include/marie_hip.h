@@ -59,6 +59,8 @@ int mhip_memcpy_dev(mhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t by
 int mhip_profile_enable(mhip_ctx* ctx, int enable);
 int mhip_profile_reset(mhip_ctx* ctx);
 int mhip_profile_read(mhip_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+/* Algorithmic FLOPs (2*MAC) of the launches of an MFMA kernel id timed since the last reset (0 for HBM-bound ids). */
+int mhip_profile_flops(mhip_ctx* ctx, int kernel_id, double* flops);
 int mhip_kernel_count(void);
 const char* mhip_kernel_name(int kernel_id);
 
@@ -215,6 +217,34 @@ int mhip_craft_detect(mhip_craft* m, const uint8_t* page_dev, int h, int w, int 
 int mhip_craft_detect_host(mhip_craft* m, const uint8_t* page_host, int h, int w, int canvas_size,
                            double mag_ratio, float text_threshold, float link_threshold, float low_text,
                            float* boxes_host, int max_boxes, int* n_boxes, float* scores_host, double* ratio_out);
+
+/* ---- ViT encoder: the DiT detector backbone (BEiT + fpn1..4) and the TrOCR image encoder ------------------------- */
+/* replaces: BEiT.forward_features, marie/boxes/dit/ditod/beit.py:706-748 (dit_base_patch16 :787-800, dit_large_patch16
+ * :803-816), and AdaptedVisionTransformer.forward_features, marie/models/unilm/trocr/deit.py:105-146.            */
+typedef struct mhip_vit mhip_vit;
+typedef struct mhip_vit_config {
+  int dim, depth, heads;   /* 768/12/12 base, 1024/24/16 large; head dim must be 64                                     */
+  int patch;               /* 16                                                                                    */
+  int pos_h, pos_w;        /* pre-training position grid: 14 x 14 (DiT, IMG_SIZE 224), 24 x 24 (TrOCR, 384)          */
+  int layer_scale;         /* blocks carry gamma_1 / gamma_2 (DiT: init_values 0.1 / 1e-5)                          */
+  int qkv_bias;            /* 0 none (TrOCR DeiT), 1 BEiT q_bias + v_bias, 2 a full qkv.bias                        */
+  int final_norm;          /* apply norm.{weight,bias} to the output tokens (TrOCR encoder)                         */
+  int fpn;                 /* 1: fpn1..fpn4 on the outputs of blocks taps[0..3] (DiT: 3,5,7,11 / 7,11,15,23)        */
+  int taps[4];
+  float ln_eps;            /* 1e-6                                                                                  */
+} mhip_vit_config;
+int mhip_vit_create(mhip_ctx* ctx, int precision, const mhip_vit_config* cfg, mhip_vit** out);
+int mhip_vit_destroy(mhip_vit* m);
+/* keys relative to the BEiT / VisionTransformer module: cls_token, pos_embed, patch_embed.proj.*, blocks.N.*, norm.*, fpnK.* */
+int mhip_vit_set_tensor(mhip_vit* m, const char* key, const float* data, const int64_t* shape, int ndim);
+int mhip_vit_finalize(mhip_vit* m);
+int mhip_vit_alloc_arena(mhip_vit* m);
+int mhip_vit_arena(mhip_vit* m, void** arena_dev, size_t* bytes);
+/* B host images u8 [th][tw][3], each placed top-left on a zero (post-normalisation) H32 x W32 canvas; pixel -> (p-127.5)/127.5,
+ * swap_rb = 1 reverses the stored channel order.  Any output may be NULL.  tokens_out fp32 [B][1 + np][dim];
+ * fpnK fp32 NHWC [B][h_K][w_K][dim] at strides 4, 8, 16, 32.                                                          */
+int mhip_vit_forward_host(mhip_vit* m, const uint8_t* imgs_host, int B, int th, int tw, int H32, int W32, int swap_rb,
+                          float* tokens_out, float* fpn0, float* fpn1, float* fpn2, float* fpn3);
 
 /* ---- word-box / line geometry of the DiT box processor (host, pure functions; no ctx) --------------------------------- */
 /* replaces: merge_boxes, marie/utils/overlap.py:268-330 (find_overlap_horizontal(center_y_overlap=0.5) :106-183,

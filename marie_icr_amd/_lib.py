@@ -30,6 +30,7 @@ _SIGNATURES = (
     ("mhip_profile_enable", _i, [_vp, _i]),
     ("mhip_profile_reset", _i, [_vp]),
     ("mhip_profile_read", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("mhip_profile_flops", _i, [_vp, _i, C.POINTER(C.c_double)]),
     ("mhip_kernel_count", _i, []),
     ("mhip_kernel_name", C.c_char_p, [_i]),
     ("mhip_conv2d_nhwc", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -58,6 +59,13 @@ _SIGNATURES = (
     ("mhip_craft_detect_host", _i, [_vp, _vp, _i, _i, _i, C.c_double, C.c_float, C.c_float, C.c_float, _vp, _i,
                                     C.POINTER(_i), _vp, C.POINTER(C.c_double)]),
     ("mhip_crop_batch", _i, [_vp, _vp, _vp, _i, _i, _vp]),
+    ("mhip_vit_create", _i, [_vp, _i, _vp, C.POINTER(_vp)]),
+    ("mhip_vit_destroy", _i, [_vp]),
+    ("mhip_vit_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
+    ("mhip_vit_finalize", _i, [_vp]),
+    ("mhip_vit_alloc_arena", _i, [_vp]),
+    ("mhip_vit_arena", _i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    ("mhip_vit_forward_host", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("mhip_merge_boxes", _i, [_vp, _i, _vp, C.POINTER(_i)]),
     ("mhip_line_merge", _i, [_vp, _i, _vp, C.POINTER(_i)]),
     ("mhip_find_line_numbers", _i, [_vp, _i, _vp, _i, _vp]),
@@ -84,6 +92,13 @@ class ConvDesc(C.Structure):
     """mirror of ``mhip_conv_desc`` (include/marie_hip.h)"""
     _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "KH", "KW", "pad", "N", "pool", "relu", "out_f32",
                                          "dil", "Cin1")]
+
+
+class VitConfig(C.Structure):
+    """mirror of mhip_vit_config (include/marie_hip.h)"""
+    _fields_ = [("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("patch", C.c_int), ("pos_h", C.c_int),
+                ("pos_w", C.c_int), ("layer_scale", C.c_int), ("qkv_bias", C.c_int), ("final_norm", C.c_int),
+                ("fpn", C.c_int), ("taps", C.c_int * 4), ("ln_eps", C.c_float)]
 
 
 class CropDesc(C.Structure):

@@ -20,12 +20,16 @@ enum MhipKernelId {
   MHIP_K_CCL = 5,         // score-map binarise + connected components + per-component statistics
   MHIP_K_CROP_BATCH = 6,  // fragment -> gray -> Pillow-exact bicubic to height 32 -> replicate pad
   MHIP_K_ATTN = 7,        // attention decoder pieces (context, LSTM cell, arg-max)
-  MHIP_K_COUNT = 8
+  MHIP_K_ATTN_FLASH = 8,  // ViT softmax attention: S^T = K Q^T -> online softmax -> O^T = V^T P^T on MFMA
+  MHIP_K_VIT_OPS = 9,     // LayerNorm, patch extraction, token/map moves (HBM-bound)
+  MHIP_K_DET_OPS = 10,    // detector heads: anchors/decode, top-k, NMS, ROIAlign
+  MHIP_K_COUNT = 11
 };
 
 struct ProfSlot {
   double total_ms = 0.0;
   int64_t launches = 0;
+  double flops = 0.0;     // algorithmic FLOPs of the launches timed so far (MFMA kernels only)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
@@ -69,6 +73,7 @@ void mhip_prof_end(mhip_ctx* ctx, int kid, hipEvent_t e0);
 // with A[m][k] = in[b][y+dy-pad][x+dx-pad][c], k = (dy*KW+dx)*Cin + c, and an optional max-pool
 // folded into the epilogue (rows are enumerated so that a pooling window is 4 / 2 consecutive m).
 enum PoolMode { POOL_NONE = 0, POOL_2x2 = 1, POOL_2x1 = 2 };
+enum ActMode { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };   // values of ConvDesc::relu
 
 struct ConvDesc {
   const void* in = nullptr;     // [B][H][W][Cin]  element type T
@@ -80,11 +85,11 @@ struct ConvDesc {
   int KH = 1, KW = 1, pad = 0;
   int N = 0;
   int pool = POOL_NONE;
-  int relu = 0;
+  int relu = 0;                 // ActMode
   int out_f32 = 0;
   int sy = 1;                   // vertical stride (horizontal stride is 1)
   int pad_x = -1;               // horizontal padding; -1 = same as `pad`
-  const void* res = nullptr;    // residual (same shape/type as out), added before the ReLU; unpooled layers only
+  const void* res = nullptr;    // residual (same shape/type as out: fp32 when out_f32), added before the ReLU; unpooled only
   int ldc = 0;                  // output row pitch in elements; 0 = N
   int dil = 1;                  // filter dilation
   const void* in2 = nullptr;    // optional second input: channels [Cin1, Cin) of a 1x1 conv over cat(in, in2)
@@ -162,3 +167,28 @@ int mhip_launch_attn_cell(mhip_ctx* ctx, int precision, const float* gctx, const
                           const float* w_onehot, const int* chars, float* c, void* h, int B);
 int mhip_launch_argmax_rows(mhip_ctx* ctx, const float* logits, int ld, int C, int* idx, int B);
 int mhip_launch_rowmax_softmax(mhip_ctx* ctx, const float* logits, int rows, int C, int* idx, float* pmax);
+
+// ------------------------------------------------------------------ ViT encoder ops (vit_ops.hip)
+int mhip_launch_layernorm(mhip_ctx* ctx, int precision, const float* x, const float* g, const float* b, void* out,
+                          int rows, int D, float eps);
+// softmax(Q K^T) V for `images` x `heads` independent (head_dim 64) problems; q is pre-scaled by head_dim^-0.5 * log2(e).
+struct AttnDesc {
+  const void* q = nullptr;    // [images*npad_q][ldq] T, head h at column h*64
+  const void* k = nullptr;    // [images*npad_k][ldk] T
+  const void* vt = nullptr;   // [heads*64][ldv] T: V transposed, column = image*npad_k + key
+  void* out = nullptr;        // [images*npad_q][ldo] T
+  int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+  int images = 0, heads = 0;
+  int npad_q = 0, npad_k = 0;  // rows per image (npad_q % 128 == 0, npad_k % 64 == 0)
+  int n_queries = 0, n_keys = 0;
+};
+int mhip_launch_attention(mhip_ctx* ctx, int precision, const AttnDesc& d);
+double mhip_attention_flops(const AttnDesc& d);
+int mhip_launch_patchify(mhip_ctx* ctx, int precision, const uint8_t* img, int th, int tw, int hp, int wp, int P,
+                         int swap_rb, float mean, float stdv, void* out, int ld);
+int mhip_launch_token_init(mhip_ctx* ctx, float* x, const float* cls_row, int B, int npad, int n_tok, int D);
+int mhip_launch_tokens_to_map(mhip_ctx* ctx, int precision, const float* x, void* out, int B, int npad, int np, int D);
+int mhip_launch_posemb_bicubic(mhip_ctx* ctx, const float* tab, int gh, int gw, float* out, int hp, int wp, int D);
+int mhip_launch_convert_rows(mhip_ctx* ctx, int precision, const void* in, float* out, int rows, int D);
+int mhip_launch_unnest(mhip_ctx* ctx, int precision, const void* in, const void* coarse, void* out, int out_f32, int B,
+                       int H, int W, int C, int nest);

@@ -275,7 +275,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float t = acc[i][j][r] * sc + bi;
-            v[r] = (p.relu && !p.res) ? fmaxf(t, 0.f) : t;   // with a residual the ReLU follows the add (copy-out)
+            if (p.relu == ACT_GELU) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));   // exact (erf) GELU
+            else if (p.relu == ACT_RELU && !p.res) t = fmaxf(t, 0.f);   // with a residual the ReLU follows the add
+            v[r] = t;
           }
           const int lr4 = wr * (MT * 16) + i * 16 + fg * 4;  // first of this lane's 4 consecutive tile rows
           if (POOL == POOL_2x2) {
@@ -314,12 +316,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
             if (oe == 4) {
               float4v a = *(float4v*)&val, r4 = *(float4v*)&rv;
 #pragma unroll
-              for (int k = 0; k < 4; ++k) { float t = a[k] + r4[k]; a[k] = p.relu ? fmaxf(t, 0.f) : t; }
+              for (int k = 0; k < 4; ++k) { float t = a[k] + r4[k]; a[k] = p.relu == ACT_RELU ? fmaxf(t, 0.f) : t; }
               val = *(uint4v*)&a;
             } else {
               half8 a = *(half8*)&val, r8 = *(half8*)&rv;
 #pragma unroll
-              for (int k = 0; k < 8; ++k) { float t = (float)a[k] + (float)r8[k]; a[k] = (_Float16)(p.relu ? fmaxf(t, 0.f) : t); }
+              for (int k = 0; k < 8; ++k) { float t = (float)a[k] + (float)r8[k]; a[k] = (_Float16)(p.relu == ACT_RELU ? fmaxf(t, 0.f) : t); }
               val = *(uint4v*)&a;
             }
           }
@@ -407,8 +409,8 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.ldc = d.ldc;
   a.Ho = (d.H + 2 * d.pad - a.dil * (d.KH - 1) - 1) / a.sy + 1;
   a.Wo = d.W + 2 * a.pad_x - a.dil * (d.KW - 1);
-  if (a.res && (d.pool != POOL_NONE || d.out_f32))
-    return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: a residual needs an unpooled output of the activation type");
+  if (a.res && d.pool != POOL_NONE) return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: a residual needs an unpooled output");
+  if (a.res && d.relu == ACT_GELU) return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: GELU is applied before any residual add");
   if (a.ldc && (a.ldc < d.N || d.pool != POOL_NONE))
     return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: bad output pitch %d", a.ldc);
   if ((a.res || a.ldc) && ((size_t)(a.ldc ? a.ldc : d.N) * (d.out_f32 ? 4 : esz)) % 16 != 0)
@@ -442,6 +444,7 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.relu = d.relu;
   a.out_f32 = d.out_f32;
   a.PH = a.PW = a.tiles_x = a.tiles_y = 0;
+  if (ctx->profiling) ctx->prof[MHIP_K_CONV_IGEMM].flops += mhip_conv_flops(d);
   {
     const int r = mhip_try_launch_conv3x3_patch(ctx, precision, d, a);   // 3x3 / pad 1 / dense: patch kernel
     if (r <= 0) return r;

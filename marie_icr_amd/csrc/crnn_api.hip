@@ -22,7 +22,8 @@ int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "lstm_rec",   "ctc_decode",
-                                                 "image_ops",  "ccl",        "crop_batch", "attn"};
+                                                 "image_ops",  "ccl",        "crop_batch", "attn",
+                                                 "attn_flash", "vit_ops",    "det_ops"};
 
 extern "C" int mhip_kernel_count(void) { return MHIP_K_COUNT; }
 extern "C" const char* mhip_kernel_name(int k) { return (k >= 0 && k < MHIP_K_COUNT) ? kKernelNames[k] : ""; }
@@ -156,7 +157,13 @@ extern "C" int mhip_profile_reset(mhip_ctx* ctx) {
   for (auto& s : ctx->prof) {
     s.total_ms = 0;
     s.launches = 0;
+    s.flops = 0;
   }
+  return MHIP_OK;
+}
+extern "C" int mhip_profile_flops(mhip_ctx* ctx, int kid, double* flops) {
+  if (!ctx || kid < 0 || kid >= MHIP_K_COUNT || !flops) return MHIP_EINVAL;
+  *flops = ctx->prof[kid].flops;
   return MHIP_OK;
 }
 extern "C" int mhip_profile_read(mhip_ctx* ctx, int kid, double* total_ms, int64_t* launches) {

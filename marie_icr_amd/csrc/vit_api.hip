@@ -1,0 +1,416 @@
+// vit_api.hip — ViT encoder (BEiT / DiT backbone with its four FPN taps, and the TrOCR DeiT encoder) behind the C ABI.
+//
+// Host-side counterpart of BEiT.forward_features (marie/boxes/dit/ditod/beit.py:706-748: PatchEmbed + bicubic abs
+// pos-emb :362-376, Block :315-341, Attention :175-260, fpn1..fpn4 :609-624) and of AdaptedVisionTransformer.
+// forward_features (marie/models/unilm/trocr/deit.py:105-146).  One object = one weight arena + the launch sequence.
+#include <math.h>
+
+#include "vit_internal.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+int gemm(mhip_ctx* ctx, int prec, const void* in, const void* w, long long M, int N, int K, const float* scale,
+         const float* bias, void* out, int act, int out_f32, const void* res = nullptr, int ldc = 0) {
+  ConvDesc c;
+  c.in = in; c.w = w; c.scale = scale; c.bias = bias; c.out = out;
+  c.B = 1; c.H = 1; c.W = (int)M; c.Cin = K; c.N = N;
+  c.relu = act; c.out_f32 = out_f32; c.res = res; c.ldc = ldc;
+  return mhip_launch_conv_igemm(ctx, prec, c);
+}
+
+std::string blk(int i, const char* s) { return "blocks." + std::to_string(i) + "." + s; }
+
+}  // namespace
+
+int mhip_gemm(mhip_ctx* ctx, int prec, const void* in, const void* w, long long M, int N, int K, const float* scale,
+              const float* bias, void* out, int act, int out_f32, const void* res, int ldc) {
+  return gemm(ctx, prec, in, w, M, N, K, scale, bias, out, act, out_f32, res, ldc);
+}
+
+// ---------------------------------------------------------------------------------------------------- lifecycle
+extern "C" int mhip_vit_create(mhip_ctx* ctx, int precision, const mhip_vit_config* cfg, mhip_vit** out) {
+  if (!ctx || !out || !cfg) return MHIP_EINVAL;
+  *out = nullptr;
+  if (precision != MHIP_PREC_F16 && precision != MHIP_PREC_F32) return mhip_fail(ctx, MHIP_EINVAL, "unknown precision %d", precision);
+  if (cfg->dim != cfg->heads * 64 || cfg->dim % 256 || cfg->dim > 1024 || cfg->depth < 1 || cfg->patch != 16 ||
+      cfg->pos_h < 1 || cfg->pos_w < 1 || cfg->qkv_bias < 0 || cfg->qkv_bias > 2)
+    return mhip_fail(ctx, MHIP_EINVAL, "vit: unsupported configuration (dim %d heads %d patch %d)", cfg->dim, cfg->heads, cfg->patch);
+  if (cfg->fpn)
+    for (int j = 0; j < 4; ++j)
+      if (cfg->taps[j] < 0 || cfg->taps[j] >= cfg->depth) return mhip_fail(ctx, MHIP_EINVAL, "vit: tap %d out of range", cfg->taps[j]);
+  mhip_vit* m = new mhip_vit();
+  m->ctx = ctx;
+  m->precision = precision;
+  m->cfg = *cfg;
+  const size_t es = m->esz(), D = cfg->dim, K0 = 3 * 16 * 16;
+  Arena& a = m->arena;
+  a.take("pe_w", D * K0 * es);
+  a.take("pe_b", D * 4);
+  a.take("pos", (size_t)cfg->pos_h * cfg->pos_w * D * 4);
+  a.take("cls", D * 4);
+  for (int i = 0; i < cfg->depth; ++i) {
+    a.take(blk(i, "ln1_g"), D * 4); a.take(blk(i, "ln1_b"), D * 4);
+    a.take(blk(i, "qk_w"), 2 * D * D * es); a.take(blk(i, "qk_b"), 2 * D * 4);
+    a.take(blk(i, "v_w"), D * D * es);
+    a.take(blk(i, "proj_w"), D * D * es); a.take(blk(i, "proj_s"), D * 4); a.take(blk(i, "proj_b"), D * 4);
+    a.take(blk(i, "ln2_g"), D * 4); a.take(blk(i, "ln2_b"), D * 4);
+    a.take(blk(i, "fc1_w"), 4 * D * D * es); a.take(blk(i, "fc1_b"), 4 * D * 4);
+    a.take(blk(i, "fc2_w"), 4 * D * D * es); a.take(blk(i, "fc2_s"), D * 4); a.take(blk(i, "fc2_b"), D * 4);
+  }
+  if (cfg->final_norm) { a.take("norm_g", D * 4); a.take("norm_b", D * 4); }
+  if (cfg->fpn)
+    for (const char* n : {"f1a", "f1b", "f2"}) {
+      a.take(std::string(n) + "_w", 4 * D * D * es);
+      a.take(std::string(n) + "_s", 4 * D * 4);
+      a.take(std::string(n) + "_b", 4 * D * 4);
+    }
+  *out = m;
+  return MHIP_OK;
+}
+
+extern "C" int mhip_vit_destroy(mhip_vit* m) {
+  if (!m) return MHIP_OK;
+  (void)hipStreamSynchronize(m->ctx->stream);
+  m->arena.release();
+  if (m->pos_dev) (void)hipFree(m->pos_dev);
+  delete m;
+  return MHIP_OK;
+}
+
+extern "C" int mhip_vit_set_tensor(mhip_vit* m, const char* key, const float* data, const int64_t* shape, int ndim) {
+  if (!m || !key) return MHIP_EINVAL;
+  std::string k(key);
+  if (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0) return MHIP_OK;
+  if (k.find("relative_position") != std::string::npos)
+    return mhip_fail(m->ctx, MHIP_EINVAL, "vit: relative position bias (%s) is not part of this build (abs pos-emb only)", key);
+  m->ready = false;
+  return m->store.set(m->ctx, k, data, shape, ndim);
+}
+
+extern "C" int mhip_vit_alloc_arena(mhip_vit* m) {
+  if (!m) return MHIP_EINVAL;
+  int rc = m->arena.alloc(m->ctx);
+  if (rc) return rc;
+  m->ready = true;
+  return MHIP_OK;
+}
+
+extern "C" int mhip_vit_arena(mhip_vit* m, void** dev, size_t* bytes) {
+  if (!m) return MHIP_EINVAL;
+  if (dev) *dev = m->arena.dev;
+  if (bytes) *bytes = m->arena.bytes;
+  return MHIP_OK;
+}
+
+// ConvTranspose2d(k=2, s=2) weight [Cin][Cout][2][2] -> GEMM weight [n = (dy*2+dx)*Cout + co][ci]
+static void pack_convT(const mhip_vit* m, Arena& a, const std::string& name, const HostTensor& w, const HostTensor& b,
+                       const float* ch_scale, const float* ch_shift) {
+  const int D = m->cfg.dim;
+  std::vector<float> tmp((size_t)4 * D * D);
+  for (int ci = 0; ci < D; ++ci)
+    for (int co = 0; co < D; ++co)
+      for (int q = 0; q < 4; ++q) tmp[((size_t)q * D + co) * D + ci] = w.data[((size_t)ci * D + co) * 4 + q];
+  Arena::put(m->precision, a.h(name + "_w"), tmp.data(), tmp.size());
+  float* s = (float*)a.h(name + "_s");
+  float* sh = (float*)a.h(name + "_b");
+  for (int q = 0; q < 4; ++q)
+    for (int co = 0; co < D; ++co) {
+      const float sc = ch_scale ? ch_scale[co] : 1.f;
+      s[q * D + co] = sc;
+      sh[q * D + co] = (ch_shift ? ch_shift[co] : 0.f) + b.data[co] * sc;
+    }
+}
+
+extern "C" int mhip_vit_finalize(mhip_vit* m) {
+  if (!m) return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  const mhip_vit_config& c = m->cfg;
+  const int D = c.dim, prec = m->precision;
+  const size_t es = m->esz();
+  Arena& a = m->arena;
+  const TensorStore& st = m->store;
+  a.begin_fill();
+  const HostTensor* pw = st.find(ctx, "patch_embed.proj.weight", {D, 3, 16, 16});
+  const HostTensor* pb = st.find(ctx, "patch_embed.proj.bias", {D});
+  const HostTensor* pos = st.find(ctx, "pos_embed", {1, 1 + c.pos_h * c.pos_w, D});
+  const HostTensor* cls = st.find(ctx, "cls_token", {1, 1, D});
+  if (!pw || !pb || !pos || !cls) return MHIP_ESTATE;
+  Arena::put(prec, a.h("pe_w"), pw->data.data(), pw->numel());
+  memcpy(a.h("pe_b"), pb->data.data(), D * 4);
+  memcpy(a.h("pos"), pos->data.data() + D, (size_t)c.pos_h * c.pos_w * D * 4);
+  for (int d = 0; d < D; ++d) ((float*)a.h("cls"))[d] = cls->data[d] + pos->data[d];
+  const float qs = 0.125f * LOG2E;   // head_dim^-0.5 (64 -> 1/8) and the exp -> exp2 change of base, folded into W_q
+  for (int i = 0; i < c.depth; ++i) {
+    const HostTensor* g1 = st.find(ctx, blk(i, "norm1.weight"), {D});
+    const HostTensor* b1 = st.find(ctx, blk(i, "norm1.bias"), {D});
+    const HostTensor* qkv = st.find(ctx, blk(i, "attn.qkv.weight"), {3 * D, D});
+    const HostTensor* pjw = st.find(ctx, blk(i, "attn.proj.weight"), {D, D});
+    const HostTensor* pjb = st.find(ctx, blk(i, "attn.proj.bias"), {D});
+    const HostTensor* g2 = st.find(ctx, blk(i, "norm2.weight"), {D});
+    const HostTensor* b2 = st.find(ctx, blk(i, "norm2.bias"), {D});
+    const HostTensor* f1w = st.find(ctx, blk(i, "mlp.fc1.weight"), {4 * D, D});
+    const HostTensor* f1b = st.find(ctx, blk(i, "mlp.fc1.bias"), {4 * D});
+    const HostTensor* f2w = st.find(ctx, blk(i, "mlp.fc2.weight"), {D, 4 * D});
+    const HostTensor* f2b = st.find(ctx, blk(i, "mlp.fc2.bias"), {D});
+    if (!g1 || !b1 || !qkv || !pjw || !pjb || !g2 || !b2 || !f1w || !f1b || !f2w || !f2b) return MHIP_ESTATE;
+    std::vector<float> qb(D, 0.f), kb(D, 0.f), vb(D, 0.f);
+    if (c.qkv_bias == 1) {
+      const HostTensor* q = st.find(ctx, blk(i, "attn.q_bias"), {D});
+      const HostTensor* v = st.find(ctx, blk(i, "attn.v_bias"), {D});
+      if (!q || !v) return MHIP_ESTATE;
+      qb = q->data; vb = v->data;
+    } else if (c.qkv_bias == 2) {
+      const HostTensor* b = st.find(ctx, blk(i, "attn.qkv.bias"), {3 * D});
+      if (!b) return MHIP_ESTATE;
+      qb.assign(b->data.begin(), b->data.begin() + D);
+      kb.assign(b->data.begin() + D, b->data.begin() + 2 * D);
+      vb.assign(b->data.begin() + 2 * D, b->data.end());
+    }
+    std::vector<float> gam1(D, 1.f), gam2(D, 1.f);
+    if (c.layer_scale) {
+      const HostTensor* ga = st.find(ctx, blk(i, "gamma_1"), {D});
+      const HostTensor* gb = st.find(ctx, blk(i, "gamma_2"), {D});
+      if (!ga || !gb) return MHIP_ESTATE;
+      gam1 = ga->data; gam2 = gb->data;
+    }
+    memcpy(a.h(blk(i, "ln1_g")), g1->data.data(), D * 4);
+    memcpy(a.h(blk(i, "ln1_b")), b1->data.data(), D * 4);
+    memcpy(a.h(blk(i, "ln2_g")), g2->data.data(), D * 4);
+    memcpy(a.h(blk(i, "ln2_b")), b2->data.data(), D * 4);
+    std::vector<float> wq((size_t)D * D);
+    for (size_t e = 0; e < wq.size(); ++e) wq[e] = qkv->data[e] * qs;
+    Arena::put(prec, a.h(blk(i, "qk_w")), wq.data(), wq.size());
+    Arena::put(prec, a.h(blk(i, "qk_w")) + (size_t)D * D * es, qkv->data.data() + (size_t)D * D, (size_t)D * D);
+    float* qkb = (float*)a.h(blk(i, "qk_b"));
+    for (int d = 0; d < D; ++d) { qkb[d] = qb[d] * qs; qkb[D + d] = kb[d]; }
+    Arena::put(prec, a.h(blk(i, "v_w")), qkv->data.data() + (size_t)2 * D * D, (size_t)D * D);
+    Arena::put(prec, a.h(blk(i, "proj_w")), pjw->data.data(), pjw->numel());
+    // softmax rows sum to one, so the value bias passes through attention unchanged:  proj(o + b_v) = proj(o) + W_p b_v
+    float* ps = (float*)a.h(blk(i, "proj_s"));
+    float* pbb = (float*)a.h(blk(i, "proj_b"));
+    for (int o = 0; o < D; ++o) {
+      double acc = pjb->data[o];
+      for (int k = 0; k < D; ++k) acc += (double)pjw->data[(size_t)o * D + k] * vb[k];
+      ps[o] = gam1[o];
+      pbb[o] = (float)acc * gam1[o];
+    }
+    Arena::put(prec, a.h(blk(i, "fc1_w")), f1w->data.data(), f1w->numel());
+    memcpy(a.h(blk(i, "fc1_b")), f1b->data.data(), (size_t)4 * D * 4);
+    Arena::put(prec, a.h(blk(i, "fc2_w")), f2w->data.data(), f2w->numel());
+    float* fs = (float*)a.h(blk(i, "fc2_s"));
+    float* fb = (float*)a.h(blk(i, "fc2_b"));
+    for (int o = 0; o < D; ++o) { fs[o] = gam2[o]; fb[o] = f2b->data[o] * gam2[o]; }
+  }
+  if (c.final_norm) {
+    const HostTensor* g = st.find(ctx, "norm.weight", {D});
+    const HostTensor* b = st.find(ctx, "norm.bias", {D});
+    if (!g || !b) return MHIP_ESTATE;
+    memcpy(a.h("norm_g"), g->data.data(), D * 4);
+    memcpy(a.h("norm_b"), b->data.data(), D * 4);
+  }
+  if (c.fpn) {
+    const HostTensor* w0 = st.find(ctx, "fpn1.0.weight", {D, D, 2, 2});
+    const HostTensor* b0 = st.find(ctx, "fpn1.0.bias", {D});
+    const HostTensor* bg = st.find(ctx, "fpn1.1.weight", {D});
+    const HostTensor* bb = st.find(ctx, "fpn1.1.bias", {D});
+    const HostTensor* bm = st.find(ctx, "fpn1.1.running_mean", {D});
+    const HostTensor* bv = st.find(ctx, "fpn1.1.running_var", {D});
+    const HostTensor* w3 = st.find(ctx, "fpn1.3.weight", {D, D, 2, 2});
+    const HostTensor* b3 = st.find(ctx, "fpn1.3.bias", {D});
+    const HostTensor* w2 = st.find(ctx, "fpn2.0.weight", {D, D, 2, 2});
+    const HostTensor* b2 = st.find(ctx, "fpn2.0.bias", {D});
+    if (!w0 || !b0 || !bg || !bb || !bm || !bv || !w3 || !b3 || !w2 || !b2) return MHIP_ESTATE;
+    std::vector<float> sc(D), sh(D);
+    for (int o = 0; o < D; ++o) {
+      sc[o] = bg->data[o] / sqrtf(bv->data[o] + 1e-5f);
+      sh[o] = bb->data[o] - bm->data[o] * sc[o];
+    }
+    pack_convT(m, a, "f1a", *w0, *b0, sc.data(), sh.data());
+    pack_convT(m, a, "f1b", *w3, *b3, nullptr, nullptr);
+    pack_convT(m, a, "f2", *w2, *b2, nullptr, nullptr);
+  }
+  int rc = a.upload(ctx);
+  if (rc) return rc;
+  m->ready = true;
+  m->store.t.clear();
+  m->pos_hp = m->pos_wp = 0;
+  return MHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- forward
+void vit_geometry(const mhip_vit* m, int H32, int W32, VitGeom* g) {
+  g->hp = H32 / m->cfg.patch;
+  g->wp = W32 / m->cfg.patch;
+  g->np = g->hp * g->wp;
+  g->n_tok = g->np + 1;
+  g->npad = (g->n_tok + 127) / 128 * 128;
+}
+
+size_t vit_workspace_bytes(const mhip_vit* m, int B, const VitGeom& g) {
+  const size_t es = m->esz(), D = m->cfg.dim, R = (size_t)B * g.npad;
+  size_t b = 0;
+  auto add = [&](size_t n) { b += (n + 255) / 256 * 256; };
+  add(R * D * 4);              // x
+  add(R * D * es);             // ln / attention output
+  add(R * 2 * D * es);         // q | k
+  add(D * R * es);             // v^T
+  add(R * D * es);             // attention output
+  add(R * 4 * D * es);         // mlp hidden; also the patch matrix
+  if (m->cfg.fpn) add(4 * (size_t)B * g.np * D * es);
+  else add(R * D * es);        // final tokens
+  return b;
+}
+
+int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int tw, int H32, int W32, int swap_rb,
+               VitRun* run) {
+  mhip_ctx* ctx = m->ctx;
+  if (!m->ready) return mhip_fail(ctx, MHIP_ESTATE, "vit: weights not finalized");
+  const mhip_vit_config& c = m->cfg;
+  const int D = c.dim, prec = m->precision, P = c.patch;
+  const size_t es = m->esz();
+  if (B < 1 || th < 1 || tw < 1 || H32 % P || W32 % P || th > H32 || tw > W32) return mhip_fail(ctx, MHIP_EINVAL, "vit: bad image geometry");
+  VitGeom g;
+  vit_geometry(m, H32, W32, &g);
+  run->g = g;
+  const Arena& a = m->arena;
+  if (m->pos_hp != g.hp || m->pos_wp != g.wp) {   // resized position table, rebuilt only when the page geometry changes
+    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->pos_dev) (void)hipFree(m->pos_dev);
+    m->pos_dev = nullptr;
+    MHIP_HIP(ctx, hipMalloc((void**)&m->pos_dev, (size_t)g.np * D * 4));
+    int rc = mhip_launch_posemb_bicubic(ctx, a.d<float>("pos"), c.pos_h, c.pos_w, m->pos_dev, g.hp, g.wp, D);
+    if (rc) return rc;
+    m->pos_hp = g.hp; m->pos_wp = g.wp;
+  }
+  const size_t R = (size_t)B * g.npad;
+  float* x = ws.take<float>(R * D * 4);
+  char* ln = ws.take(R * D * es);
+  char* qk = ws.take(R * 2 * D * es);
+  char* vt = ws.take(D * R * es);
+  char* ao = ws.take(R * D * es);
+  char* hid = ws.take(R * 4 * D * es);
+  run->x = x;
+  int rc;
+  // patches -> hid (as the [B*np][768] patch matrix) -> x rows 1.. with bias + resized position table
+  const int K0 = 3 * P * P;
+  for (int b = 0; b < B; ++b) {
+    char* A = hid + (size_t)b * g.np * K0 * es;
+    if ((rc = mhip_launch_patchify(ctx, prec, imgs + (size_t)b * th * tw * 3, th, tw, g.hp, g.wp, P, swap_rb, 127.5f, 127.5f, A, K0))) return rc;
+    if ((rc = gemm(ctx, prec, A, a.d("pe_w"), g.np, D, K0, nullptr, a.d<float>("pe_b"), x + ((size_t)b * g.npad + 1) * D, ACT_NONE, 1, m->pos_dev))) return rc;
+  }
+  if ((rc = mhip_launch_token_init(ctx, x, a.d<float>("cls"), B, g.npad, g.n_tok, D))) return rc;
+  int tap_at = 0;
+  if (c.fpn) for (int j = 0; j < 4; ++j) run->tap[j] = ws.take((size_t)B * g.np * D * es);
+  for (int i = 0; i < c.depth; ++i) {
+    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>(blk(i, "ln1_g")), a.d<float>(blk(i, "ln1_b")), ln, (int)R, D, c.ln_eps))) return rc;
+    if ((rc = gemm(ctx, prec, ln, a.d(blk(i, "qk_w")), (long long)R, 2 * D, D, nullptr, a.d<float>(blk(i, "qk_b")), qk, ACT_NONE, 0))) return rc;
+    if ((rc = gemm(ctx, prec, a.d(blk(i, "v_w")), ln, D, (int)R, D, nullptr, nullptr, vt, ACT_NONE, 0))) return rc;   // V^T = W_v X^T
+    AttnDesc ad;
+    ad.q = qk; ad.k = qk + (size_t)D * es; ad.vt = vt; ad.out = ao;
+    ad.ldq = ad.ldk = 2 * D; ad.ldv = (int)R; ad.ldo = D;
+    ad.images = B; ad.heads = c.heads; ad.npad_q = ad.npad_k = g.npad; ad.n_queries = ad.n_keys = g.n_tok;
+    if ((rc = mhip_launch_attention(ctx, prec, ad))) return rc;
+    if ((rc = gemm(ctx, prec, ao, a.d(blk(i, "proj_w")), (long long)R, D, D, a.d<float>(blk(i, "proj_s")), a.d<float>(blk(i, "proj_b")), x, ACT_NONE, 1, x))) return rc;
+    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>(blk(i, "ln2_g")), a.d<float>(blk(i, "ln2_b")), ln, (int)R, D, c.ln_eps))) return rc;
+    if ((rc = gemm(ctx, prec, ln, a.d(blk(i, "fc1_w")), (long long)R, 4 * D, D, nullptr, a.d<float>(blk(i, "fc1_b")), hid, ACT_GELU, 0))) return rc;
+    if ((rc = gemm(ctx, prec, hid, a.d(blk(i, "fc2_w")), (long long)R, D, 4 * D, a.d<float>(blk(i, "fc2_s")), a.d<float>(blk(i, "fc2_b")), x, ACT_NONE, 1, x))) return rc;
+    if (c.fpn)
+      for (int j = 0; j < 4; ++j)
+        if (c.taps[j] == i) {
+          if ((rc = mhip_launch_tokens_to_map(ctx, prec, x, run->tap[j], B, g.npad, g.np, D))) return rc;
+          ++tap_at;
+        }
+  }
+  run->tokens = nullptr;
+  if (c.final_norm) {
+    run->tokens = ws.take(R * D * es);
+    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>("norm_g"), a.d<float>("norm_b"), run->tokens, (int)R, D, c.ln_eps))) return rc;
+  }
+  (void)tap_at;
+  return MHIP_OK;
+}
+
+size_t vit_fpn_workspace_bytes(const mhip_vit* m, int B, const VitGeom& g) {
+  const size_t es = m->esz(), D = m->cfg.dim, M = (size_t)B * g.np;
+  return (4 * M * D * es + 256) + (16 * M * D * es + 256) + (4 * M * D * es + 256) + (M / 4 * D * es + 256) + 4096;
+}
+
+// fpn1..fpn4 on the four taps.  ConvTranspose2d(2, 2) is per-pixel: a GEMM to 4*D columns whose output, read as
+// [4*rows][D], is the 2x-upsampled map in NESTED order (row = parent*4 + dy*2 + dx).  Consumers that are per-pixel
+// themselves (the FPN lateral 1x1) take it as is; mhip_launch_unnest restores raster order.
+int vit_fpn(mhip_vit* m, Carver& ws, int B, const VitRun& run, VitFpnOut* out) {
+  mhip_ctx* ctx = m->ctx;
+  const int D = m->cfg.dim, prec = m->precision;
+  const size_t es = m->esz();
+  const VitGeom& g = run.g;
+  const long long M = (long long)B * g.np;
+  const Arena& a = m->arena;
+  char* t1 = ws.take(4 * M * D * es);
+  char* o1 = ws.take(16 * M * D * es);
+  char* o2 = ws.take(4 * M * D * es);
+  int rc;
+  if ((rc = gemm(ctx, prec, run.tap[0], a.d("f1a_w"), M, 4 * D, D, a.d<float>("f1a_s"), a.d<float>("f1a_b"), t1, ACT_GELU, 0))) return rc;
+  if ((rc = gemm(ctx, prec, t1, a.d("f1b_w"), 4 * M, 4 * D, D, a.d<float>("f1b_s"), a.d<float>("f1b_b"), o1, ACT_NONE, 0))) return rc;
+  if ((rc = gemm(ctx, prec, run.tap[1], a.d("f2_w"), M, 4 * D, D, a.d<float>("f2_s"), a.d<float>("f2_b"), o2, ACT_NONE, 0))) return rc;
+  out->level[0] = o1; out->nest[0] = 2;
+  out->level[1] = o2; out->nest[1] = 1;
+  out->level[2] = run.tap[2]; out->nest[2] = 0;
+  const int h4 = g.hp / 2, w4 = g.wp / 2;   // MaxPool2d(2, 2) floors odd sizes
+  char* o4 = ws.take((size_t)B * h4 * w4 * D * es);
+  if ((rc = mhip_launch_maxpool(ctx, prec, 2, run.tap[3], o4, B, g.hp, g.wp, D))) return rc;
+  out->level[3] = o4; out->nest[3] = 0;
+  out->h[0] = 4 * g.hp; out->w[0] = 4 * g.wp;
+  out->h[1] = 2 * g.hp; out->w[1] = 2 * g.wp;
+  out->h[2] = g.hp; out->w[2] = g.wp;
+  out->h[3] = h4; out->w[3] = w4;
+  return MHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- test / host entry
+extern "C" int mhip_vit_forward_host(mhip_vit* m, const uint8_t* imgs_host, int B, int th, int tw, int H32, int W32,
+                                     int swap_rb, float* tokens_out, float* fpn0, float* fpn1, float* fpn2, float* fpn3) {
+  if (!m || !imgs_host) return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  VitGeom g;
+  vit_geometry(m, H32, W32, &g);
+  const size_t D = m->cfg.dim;
+  const size_t img_bytes = (size_t)B * th * tw * 3;
+  const size_t out_f32 = m->cfg.fpn ? (size_t)B * 16 * g.np * D * 4 : (size_t)B * g.npad * D * 4;
+  const size_t need = vit_workspace_bytes(m, B, g) + (m->cfg.fpn ? vit_fpn_workspace_bytes(m, B, g) : 0) + img_bytes + out_f32 + 4096;
+  int rc = mhip_ensure_workspace(ctx, need);
+  if (rc) return rc;
+  Carver ws(ctx->ws);
+  uint8_t* imgs = ws.take<uint8_t>(img_bytes);
+  float* stage = ws.take<float>(out_f32);
+  MHIP_HIP(ctx, hipMemcpyAsync(imgs, imgs_host, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+  VitRun run;
+  if ((rc = vit_encode(m, ws, imgs, B, th, tw, H32, W32, swap_rb, &run))) return rc;
+  if (tokens_out) {
+    // final tokens (after the last norm if configured, else the residual stream), valid rows only
+    for (int b = 0; b < B; ++b) {
+      if (m->cfg.final_norm) {
+        if ((rc = mhip_launch_convert_rows(ctx, m->precision, run.tokens + (size_t)b * g.npad * D * m->esz(), stage, g.n_tok, (int)D))) return rc;
+        MHIP_HIP(ctx, hipMemcpyAsync(tokens_out + (size_t)b * g.n_tok * D, stage, (size_t)g.n_tok * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        MHIP_HIP(ctx, hipMemcpyAsync(tokens_out + (size_t)b * g.n_tok * D, run.x + (size_t)b * g.npad * D, (size_t)g.n_tok * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+      }
+    }
+  }
+  if (m->cfg.fpn) {
+    VitFpnOut fo;
+    if ((rc = vit_fpn(m, ws, B, run, &fo))) return rc;
+    float* outs[4] = {fpn0, fpn1, fpn2, fpn3};
+    for (int j = 0; j < 4; ++j) {
+      if (!outs[j]) continue;
+      if ((rc = mhip_launch_unnest(ctx, m->precision, fo.level[j], nullptr, stage, 1, B, fo.h[j], fo.w[j], (int)D, fo.nest[j]))) return rc;
+      MHIP_HIP(ctx, hipMemcpyAsync(outs[j], stage, (size_t)B * fo.h[j] * fo.w[j] * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+      MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MHIP_OK;
+}

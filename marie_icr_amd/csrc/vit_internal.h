@@ -1,0 +1,45 @@
+// vit_internal.h — the ViT encoder object as the composite models (DiT detector, TrOCR recognizer) see it.
+#pragma once
+#include "weights_util.h"
+
+struct mhip_vit {
+  mhip_ctx* ctx = nullptr;
+  int precision = MHIP_PREC_F16;
+  mhip_vit_config cfg{};
+  TensorStore store;
+  Arena arena;
+  float* pos_dev = nullptr;   // position table resized to the current patch grid
+  int pos_hp = 0, pos_wp = 0;
+  bool ready = false;
+  size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
+};
+
+struct VitGeom {
+  int hp, wp, np;   // patch grid
+  int n_tok;        // 1 + np
+  int npad;         // rows per image (multiple of 128)
+};
+
+struct VitRun {
+  VitGeom g;
+  float* x = nullptr;         // fp32 residual stream [B*npad][D]
+  char* tap[4] = {nullptr};   // T [B*np][D] patch tokens after blocks cfg.taps[j]
+  char* tokens = nullptr;     // T [B*npad][D] after the final norm (final_norm models)
+};
+
+struct VitFpnOut {
+  char* level[4];   // T, D channels: strides 4, 8, 16, 32
+  int nest[4];      // 2 / 1 / 0: nested 2x2 row order depth (see vit_fpn)
+  int h[4], w[4];
+};
+
+void vit_geometry(const mhip_vit* m, int H32, int W32, VitGeom* g);
+size_t vit_workspace_bytes(const mhip_vit* m, int B, const VitGeom& g);
+size_t vit_fpn_workspace_bytes(const mhip_vit* m, int B, const VitGeom& g);
+// imgs: B device images u8 [th][tw][3] placed on a zero canvas H32 x W32 (after normalisation)
+int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int tw, int H32, int W32, int swap_rb,
+               VitRun* run);
+int vit_fpn(mhip_vit* m, Carver& ws, int B, const VitRun& run, VitFpnOut* out);
+
+int mhip_gemm(mhip_ctx* ctx, int prec, const void* in, const void* w, long long M, int N, int K, const float* scale,
+              const float* bias, void* out, int act, int out_f32, const void* res = nullptr, int ldc = 0);

@@ -332,3 +332,70 @@ def make_icr_state(seed: int = 0, num_class: int = 96, logit_gain: float = 16.0)
     st["Prediction.generator.weight"] = uni((num_class, HIDDEN), logit_gain * np.sqrt(3.0 / HIDDEN))
     st["Prediction.generator.bias"] = uni((num_class,), 0.1)
     return st
+
+
+# ------------------------------------------------------------------------------------------------ ViT / DiT backbone
+def make_vit_state(seed: int = 0, dim: int = 768, depth: int = 12, heads: int = 12, pos_hw=(14, 14), layer_scale=True,
+                   qkv_bias: int = 1, fpn: bool = True, final_norm: bool = False) -> Dict[str, np.ndarray]:
+    """Seeded BEiT / DiT (or DeiT when ``qkv_bias != 1``) weights under the reference module's own key names
+    (marie/boxes/dit/ditod/beit.py:564-640).  Gains are chosen so attention is peaked and every branch contributes at
+    O(1) — a much harder numerical case than the 0.02-std initialisation of an untrained checkpoint."""
+    rng = np.random.Generator(np.random.PCG64(seed + 4256233))
+    st: Dict[str, np.ndarray] = {}
+
+    def uni(shape, bound):
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    D = dim
+    st["cls_token"] = uni((1, 1, D), 0.5)
+    st["pos_embed"] = uni((1, 1 + pos_hw[0] * pos_hw[1], D), 0.5)
+    st["patch_embed.proj.weight"] = uni((D, 3, 16, 16), np.sqrt(3.0 / 768) * 2.0)
+    st["patch_embed.proj.bias"] = uni((D,), 0.1)
+    for i in range(depth):
+        p = f"blocks.{i}."
+        st[p + "norm1.weight"] = rng.uniform(0.7, 1.3, size=(D,)).astype(np.float32)
+        st[p + "norm1.bias"] = uni((D,), 0.1)
+        st[p + "attn.qkv.weight"] = uni((3 * D, D), 2.0 * np.sqrt(3.0 / D))
+        if qkv_bias == 1:
+            st[p + "attn.q_bias"] = uni((D,), 0.2)
+            st[p + "attn.v_bias"] = uni((D,), 0.2)
+        elif qkv_bias == 2:
+            st[p + "attn.qkv.bias"] = uni((3 * D,), 0.2)
+        st[p + "attn.proj.weight"] = uni((D, D), np.sqrt(3.0 / D))
+        st[p + "attn.proj.bias"] = uni((D,), 0.1)
+        st[p + "norm2.weight"] = rng.uniform(0.7, 1.3, size=(D,)).astype(np.float32)
+        st[p + "norm2.bias"] = uni((D,), 0.1)
+        st[p + "mlp.fc1.weight"] = uni((4 * D, D), np.sqrt(3.0 / D))
+        st[p + "mlp.fc1.bias"] = uni((4 * D,), 0.1)
+        st[p + "mlp.fc2.weight"] = uni((D, 4 * D), np.sqrt(3.0 / (4 * D)))
+        st[p + "mlp.fc2.bias"] = uni((D,), 0.1)
+        if layer_scale:
+            st[p + "gamma_1"] = rng.uniform(0.2, 0.6, size=(D,)).astype(np.float32)
+            st[p + "gamma_2"] = rng.uniform(0.2, 0.6, size=(D,)).astype(np.float32)
+    if final_norm:
+        st["norm.weight"] = rng.uniform(0.7, 1.3, size=(D,)).astype(np.float32)
+        st["norm.bias"] = uni((D,), 0.1)
+    if fpn:
+        for name in ("fpn1.0", "fpn1.3", "fpn2.0"):
+            st[name + ".weight"] = uni((D, D, 2, 2), np.sqrt(3.0 / D))
+            st[name + ".bias"] = uni((D,), 0.1)
+        st["fpn1.1.weight"] = rng.uniform(0.6, 1.4, size=(D,)).astype(np.float32)
+        st["fpn1.1.bias"] = uni((D,), 0.2)
+        st["fpn1.1.running_mean"] = uni((D,), 0.3)
+        st["fpn1.1.running_var"] = rng.uniform(0.5, 1.5, size=(D,)).astype(np.float32)
+    return st
+
+
+def make_image_u8(seed: int, n: int, h: int, w: int) -> np.ndarray:
+    """(n, h, w, 3) uint8: smooth blobs + noise, deterministic."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    out = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        img = rng.uniform(0, 255, size=(h, w, 3)).astype(np.float32) * 0.35
+        for _ in range(6):
+            cy, cx, s = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(4, 0.3 * max(h, w))
+            amp = rng.uniform(-160, 160, size=3).astype(np.float32)
+            img += np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))[..., None] * amp
+        out[i] = np.clip(img + 80, 0, 255).astype(np.uint8)
+    return out

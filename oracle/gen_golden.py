@@ -253,9 +253,65 @@ def gen_geometry(out_dir):
     np.savez_compressed(os.path.join(out_dir, "geometry.npz"), **out)
 
 
+def _load_ref_beit():
+    """beit.py, unmodified, by path; its ``from timm.models.layers import drop_path, to_2tuple, trunc_normal_`` is
+    satisfied by three pass-through helpers — none of them takes part in an eval forward."""
+    import importlib.util
+    import types
+
+    for name in ("timm", "timm.models", "timm.models.layers"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    lay = sys.modules["timm.models.layers"]
+    lay.drop_path = lambda x, p=0.0, training=False: x
+    lay.to_2tuple = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    lay.trunc_normal_ = lambda t, std=1.0: torch.nn.init.trunc_normal_(t, std=std)
+    spec = importlib.util.spec_from_file_location("ref_beit", "/root/reference/marie/boxes/dit/ditod/beit.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+VIT_GOLDEN_CASES = (
+    # tag, dim, depth, heads, taps, (th, tw) image, (H32, W32) canvas, weight seed, image seed, batch
+    ("small", 256, 4, 4, (0, 1, 2, 3), (90, 60), (96, 64), 0, 0, 2),
+    ("base", 768, 12, 12, (3, 5, 7, 11), (120, 96), (128, 96), 1, 1, 1),
+)
+
+
+def gen_vit(out_dir):
+    from functools import partial
+
+    from marie_icr_amd.weights import make_image_u8, make_vit_state
+    from oracle.vit_torch import TorchVitOracle
+
+    beit = _load_ref_beit()
+    for tag, dim, depth, heads, taps, (th, tw), (H32, W32), wseed, iseed, B in VIT_GOLDEN_CASES:
+        st = make_vit_state(wseed, dim, depth, heads)
+        m = beit.BEiT(img_size=[224, 224], patch_size=16, embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=4,
+                      qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), init_values=0.1,
+                      out_features=[f"layer{t}" for t in taps], drop_path_rate=0.1, use_abs_pos_emb=True,
+                      use_checkpoint=False).eval()
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=False)
+        assert not unexpected and all("num_batches_tracked" in k for k in missing), (missing, unexpected)
+        imgs = make_image_u8(iseed, B, th, tw)
+        x = TorchVitOracle.preprocess(imgs, H32, W32, swap_rb=True)
+        with torch.no_grad():
+            feats = m.forward_features(x)
+        outs = [feats[f"layer{t}"].numpy() for t in taps]
+        step = 1 if tag == "small" else 4        # keep the base fixture small: every 4th channel of each tap
+        np.savez_compressed(os.path.join(out_dir, f"vit_{tag}.npz"), weight_seed=wseed, image_seed=iseed,
+                            weight_sha256=state_checksum(st), dim=dim, depth=depth, heads=heads, taps=np.asarray(taps),
+                            image_hw=np.asarray([th, tw]), canvas_hw=np.asarray([H32, W32]), batch=B, channel_step=step,
+                            **{f"fpn{j}": o[:, ::step].astype(np.float32) for j, o in enumerate(outs)})
+        print("vit", tag, [o.shape for o in outs], [float(np.abs(o).max()) for o in outs])
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if "--vit-only" in sys.argv:
+        gen_vit(out_dir)
+        return
     if "--geometry-only" in sys.argv:
         gen_geometry(out_dir)
         return

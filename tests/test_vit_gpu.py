@@ -1,0 +1,81 @@
+"""GPU parity of the ViT encoder stack (LayerNorm, MFMA attention, GEMM epilogues, patch embed, fpn heads) through the
+C ABI: fp32 mode against goldens from the reference's beit.py; f16 (production) mode against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from marie_icr_amd.weights import make_image_u8, make_vit_state
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from marie_icr_amd._lib import Context
+
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _case(tag):
+    g = np.load(os.path.join(GOLD, f"vit_{tag}.npz"))
+    st = make_vit_state(int(g["weight_seed"]), int(g["dim"]), int(g["depth"]), int(g["heads"]))
+    imgs = make_image_u8(int(g["image_seed"]), int(g["batch"]), int(g["image_hw"][0]), int(g["image_hw"][1]))
+    return g, st, imgs
+
+
+@pytest.mark.parametrize("tag", ["small", "base"])
+def test_fp32_matches_reference_golden(ctx, tag):
+    from marie_icr_amd._lib import PREC_F32
+    from marie_icr_amd.vit import VitModel, make_config
+
+    g, st, imgs = _case(tag)
+    m = VitModel(ctx, make_config(int(g["dim"]), int(g["depth"]), int(g["heads"]), g["taps"].tolist()), st, PREC_F32)
+    out = m.forward_host(imgs, g["canvas_hw"])
+    step = int(g["channel_step"])
+    for j, f in enumerate(out["fpn"]):
+        ref = np.transpose(g[f"fpn{j}"], (0, 2, 3, 1))
+        err = np.abs(f[..., ::step] - ref).max()
+        assert err <= 1e-3, (j, err)
+    m.close()
+
+
+@pytest.mark.parametrize("tag", ["small", "base"])
+def test_f16_close_to_reference_golden(ctx, tag):
+    from marie_icr_amd._lib import PREC_F16
+    from marie_icr_amd.vit import VitModel, make_config
+
+    g, st, imgs = _case(tag)
+    m = VitModel(ctx, make_config(int(g["dim"]), int(g["depth"]), int(g["heads"]), g["taps"].tolist()), st, PREC_F16)
+    out = m.forward_host(imgs, g["canvas_hw"])
+    step = int(g["channel_step"])
+    for j, f in enumerate(out["fpn"]):
+        ref = np.transpose(g[f"fpn{j}"], (0, 2, 3, 1))
+        err = np.abs(f[..., ::step] - ref)
+        # f16 operands through 12 residual blocks: 2 % of the activation range at worst, 0.3 % on average
+        assert err.max() <= 0.02 * np.abs(ref).max() + 0.02, (j, err.max(), np.abs(ref).max())
+        assert err.mean() <= 0.003 * np.abs(ref).max(), (j, err.mean())
+    m.close()
+
+
+def test_deit_variant_vs_oracle(ctx):
+    """TrOCR encoder flavour: no layer scale, full qkv bias, final norm, 24 x 24 position grid used at its own size,
+    plus a key count (577) that is not a multiple of the 64-key tile (mask path)."""
+    from marie_icr_amd._lib import PREC_F16, PREC_F32
+    from marie_icr_amd.vit import VitModel, make_config
+    from oracle.vit_torch import TorchVitOracle
+
+    st = make_vit_state(5, 256, 3, 4, pos_hw=(24, 24), layer_scale=False, qkv_bias=2, fpn=False, final_norm=True)
+    imgs = make_image_u8(9, 2, 384, 384)
+    o = TorchVitOracle(st, 4, pos_hw=(24, 24), taps=())
+    ref, _ = o.tokens(o.preprocess(imgs, 384, 384, swap_rb=False))
+    ref = ref.numpy()
+    cfg = make_config(256, 3, 4, pos_hw=(24, 24), layer_scale=0, qkv_bias=2, final_norm=1, fpn=0)
+    for prec, tol in ((PREC_F32, 1e-3), (PREC_F16, 0.03)):
+        m = VitModel(ctx, cfg, st, prec)
+        got = m.forward_host(imgs, (384, 384), swap_rb=False, want_tokens=True, want_fpn=False)["tokens"]
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (prec, np.abs(got - ref).max())
+        m.close()
