@@ -218,6 +218,14 @@ int mhip_craft_detect_host(mhip_craft* m, const uint8_t* page_host, int h, int w
                            double mag_ratio, float text_threshold, float link_threshold, float low_text,
                            float* boxes_host, int max_boxes, int* n_boxes, float* scores_host, double* ratio_out);
 
+/* ---- Pillow-exact 8-bit resize (antialiased BILINEAR / BICUBIC) of RGB images ------------------------------------------ */
+#define MHIP_PIL_BILINEAR 2   /* PIL.Image.BILINEAR */
+#define MHIP_PIL_BICUBIC 3    /* PIL.Image.BICUBIC  */
+/* replaces: ResizeShortestEdge/ResizeTransform's PIL resize (marie/detectron/detector.py:103-105) and TrOCR's
+ * im.resize((384, 384), BICUBIC) (marie/document/trocr_ocr_processor.py:116-118).  Host u8 [sh][sw][3] -> [dh][dw][3]. */
+int mhip_pil_resize_rgb_host(mhip_ctx* ctx, const uint8_t* src_host, int sh, int sw, uint8_t* dst_host, int dh, int dw,
+                             int filter);
+
 /* ---- ViT encoder: the DiT detector backbone (BEiT + fpn1..4) and the TrOCR image encoder ------------------------- */
 /* replaces: BEiT.forward_features, marie/boxes/dit/ditod/beit.py:706-748 (dit_base_patch16 :787-800, dit_large_patch16
  * :803-816), and AdaptedVisionTransformer.forward_features, marie/models/unilm/trocr/deit.py:105-146.            */
@@ -245,6 +253,61 @@ int mhip_vit_arena(mhip_vit* m, void** arena_dev, size_t* bytes);
  * fpnK fp32 NHWC [B][h_K][w_K][dim] at strides 4, 8, 16, 32.                                                          */
 int mhip_vit_forward_host(mhip_vit* m, const uint8_t* imgs_host, int B, int th, int tw, int H32, int W32, int swap_rb,
                           float* tokens_out, float* fpn0, float* fpn1, float* fpn2, float* fpn3);
+
+/* ---- DiT Mask R-CNN text detector (BoxProcessorUlimDit's model) ------------------------------------------------------- */
+/* replaces: OptimizedDetectronPredictor.invoke_model, marie/detectron/detector.py:83-147 (model built by
+ * build_vit_fpn_backbone, marie/boxes/dit/ditod/backbone.py:131-153; config/zoo/unilm/dit/text_detection/ YAMLs).       */
+typedef struct mhip_dit mhip_dit;
+typedef struct mhip_dit_config {
+  int model;                 /* 0 dit_base_patch16 (mask_rcnn_dit_base.yaml), 1 dit_large_patch16 (mask_rcnn_dit_prod.yaml) */
+  int min_size_test;         /* INPUT.MIN_SIZE_TEST 800                                                             */
+  int max_size_test;         /* INPUT.MAX_SIZE_TEST 1333 (default) / 4000 (prod)                                    */
+  int detections_per_image;  /* TEST.DETECTIONS_PER_IMAGE 2000 / 2500                                               */
+  float anchor_sizes[5];     /* ANCHOR_GENERATOR.SIZES 4, 8, 16, 32, 64                                             */
+  float aspect_ratios[3];    /* ANCHOR_GENERATOR.ASPECT_RATIOS 1.5, 3.5, 6.5                                        */
+  float rpn_nms_thresh;      /* RPN.NMS_THRESH 0.7                                                                  */
+  float score_thresh;        /* ROI_HEADS.SCORE_THRESH_TEST 0.05                                                    */
+  float nms_thresh;          /* ROI_HEADS.NMS_THRESH_TEST 0.5                                                       */
+} mhip_dit_config;
+int mhip_dit_default_config(int model, mhip_dit_config* cfg);
+/* ResizeShortestEdge output (nh, nw) and the /32 canvas for an h x w page */
+int mhip_dit_resized_shape(const mhip_dit_config* cfg, int h, int w, int* nh, int* nw, int* H32, int* W32);
+int mhip_dit_create(mhip_ctx* ctx, int precision, const mhip_dit_config* cfg, mhip_dit** out);
+int mhip_dit_destroy(mhip_dit* m);
+/* detectron2 checkpoint keys ("backbone.bottom_up.backbone.*", "backbone.fpn_*", "proposal_generator.rpn_head.*",
+ * "roi_heads.box_head.*", "roi_heads.box_predictor.*"; mask-head keys are accepted and ignored)                          */
+int mhip_dit_set_tensor(mhip_dit* m, const char* key, const float* data, const int64_t* shape, int ndim);
+int mhip_dit_finalize(mhip_dit* m);
+int mhip_dit_alloc_arena(mhip_dit* m);
+int mhip_dit_arena(mhip_dit* m, int which /* 0 backbone, 1 heads */, void** arena_dev, size_t* bytes);
+size_t mhip_dit_workspace_bytes(mhip_dit* m, int B, int h, int w);
+/* B device pages u8 BGR [h][w][3] of one size -> per page up to 1000 boxes xyxy fp32 in page coordinates, score-ordered.
+ * boxes_host [B][1000][4], scores_host [B][1000] (may be NULL), counts_host [B].                                      */
+int mhip_dit_detect(mhip_dit* m, const uint8_t* const* pages_dev, int B, int h, int w, float* boxes_host,
+                    float* scores_host, int* counts_host);
+int mhip_dit_detect_host(mhip_dit* m, const uint8_t* pages_host, int B, int h, int w, float* boxes_host,
+                         float* scores_host, int* counts_host);
+/* one page plus the intermediates the parity tests compare: FPN maps p2..p6 fp32 NHWC and the RPN proposals (any NULL) */
+int mhip_dit_debug_host(mhip_dit* m, const uint8_t* page_host, int h, int w, float* boxes_host, float* scores_host,
+                        int* count_host, float* p2, float* p3, float* p4, float* p5, float* p6, float* prop_boxes,
+                        float* prop_scores, int* prop_count);
+/* The detectron2 stages of the detector on caller-supplied host inputs (each also used by the parity tests):
+ * RPN.predict_proposals for one image — heads_host[l] fp32 [H[l]*W[l]][16] (3 objectness logits, 3 x 4 deltas, 1 pad) for
+ * p2..p6 -> up to 1000 proposals xyxy + logits, score-ordered;                                                          */
+int mhip_rpn_proposals_host(mhip_ctx* ctx, const float* const* heads_host, const int* H, const int* W, const int* strides,
+                            const float* anchor_sizes, const float* aspect_ratios, int img_h, int img_w, float nms_thresh,
+                            float* boxes_out, float* scores_out, int* count_out);
+/* ROIPooler (7x7 ROIAlignV2, sampling_ratio 0, levels by box size) — feats_host[l] fp32 NHWC at strides 4..32,
+ * rois [n][4] (n <= 1000) -> pooled fp32 [n][49*C] with k = bin*C + c;                                                  */
+int mhip_roi_align_host(mhip_ctx* ctx, const float* const* feats_host, const int* H, const int* W, int C,
+                        const float* rois_host, int n, float* pooled_out);
+/* FastRCNNOutputLayers.inference + detector_postprocess — head_host [n][8] (2 class scores, 4 deltas, 2 pad).           */
+int mhip_det_final_host(mhip_ctx* ctx, const float* head_host, const float* rois_host, int n, int img_h, int img_w,
+                        int page_h, int page_w, float score_thresh, float nms_thresh, int max_det, float* boxes_out,
+                        float* scores_out, int* count_out);
+/* replaces: blackout_bboxes, marie/boxes/dit/ulim_dit_box_processor.py:161-198, in place on a device page (BGR).        */
+int mhip_blackout_bboxes(mhip_ctx* ctx, uint8_t* page_dev, int h, int w, const int32_t* boxes_xyxy_host, int n,
+                         int* changed);
 
 /* ---- word-box / line geometry of the DiT box processor (host, pure functions; no ctx) --------------------------------- */
 /* replaces: merge_boxes, marie/utils/overlap.py:268-330 (find_overlap_horizontal(center_y_overlap=0.5) :106-183,

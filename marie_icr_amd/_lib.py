@@ -59,6 +59,7 @@ _SIGNATURES = (
     ("mhip_craft_detect_host", _i, [_vp, _vp, _i, _i, _i, C.c_double, C.c_float, C.c_float, C.c_float, _vp, _i,
                                     C.POINTER(_i), _vp, C.POINTER(C.c_double)]),
     ("mhip_crop_batch", _i, [_vp, _vp, _vp, _i, _i, _vp]),
+    ("mhip_pil_resize_rgb_host", _i, [_vp, _vp, _i, _i, _vp, _i, _i, _i]),
     ("mhip_vit_create", _i, [_vp, _i, _vp, C.POINTER(_vp)]),
     ("mhip_vit_destroy", _i, [_vp]),
     ("mhip_vit_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
@@ -66,6 +67,22 @@ _SIGNATURES = (
     ("mhip_vit_alloc_arena", _i, [_vp]),
     ("mhip_vit_arena", _i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
     ("mhip_vit_forward_host", _i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_dit_default_config", _i, [_i, _vp]),
+    ("mhip_dit_resized_shape", _i, [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    ("mhip_dit_create", _i, [_vp, _i, _vp, C.POINTER(_vp)]),
+    ("mhip_dit_destroy", _i, [_vp]),
+    ("mhip_dit_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
+    ("mhip_dit_finalize", _i, [_vp]),
+    ("mhip_dit_alloc_arena", _i, [_vp]),
+    ("mhip_dit_arena", _i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
+    ("mhip_dit_workspace_bytes", _sz, [_vp, _i, _i, _i]),
+    ("mhip_dit_detect", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    ("mhip_dit_detect_host", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    ("mhip_dit_debug_host", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_rpn_proposals_host", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp]),
+    ("mhip_roi_align_host", _i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    ("mhip_det_final_host", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, _i, _vp, _vp, _vp]),
+    ("mhip_blackout_bboxes", _i, [_vp, _vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     ("mhip_merge_boxes", _i, [_vp, _i, _vp, C.POINTER(_i)]),
     ("mhip_line_merge", _i, [_vp, _i, _vp, C.POINTER(_i)]),
     ("mhip_find_line_numbers", _i, [_vp, _i, _vp, _i, _vp]),
@@ -99,6 +116,13 @@ class VitConfig(C.Structure):
     _fields_ = [("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("patch", C.c_int), ("pos_h", C.c_int),
                 ("pos_w", C.c_int), ("layer_scale", C.c_int), ("qkv_bias", C.c_int), ("final_norm", C.c_int),
                 ("fpn", C.c_int), ("taps", C.c_int * 4), ("ln_eps", C.c_float)]
+
+
+class DitConfig(C.Structure):
+    """mirror of mhip_dit_config (include/marie_hip.h)"""
+    _fields_ = [("model", C.c_int), ("min_size_test", C.c_int), ("max_size_test", C.c_int),
+                ("detections_per_image", C.c_int), ("anchor_sizes", C.c_float * 5), ("aspect_ratios", C.c_float * 3),
+                ("rpn_nms_thresh", C.c_float), ("score_thresh", C.c_float), ("nms_thresh", C.c_float)]
 
 
 class CropDesc(C.Structure):
@@ -204,7 +228,10 @@ class Context:
             ms = C.c_double()
             n = C.c_int64()
             check(self.h, self.lib.mhip_profile_read(self.h, k, C.byref(ms), C.byref(n)), "mhip_profile_read")
-            out[self.lib.mhip_kernel_name(k).decode()] = {"id": k, "total_ms": ms.value, "launches": n.value}
+            fl = C.c_double()
+            check(self.h, self.lib.mhip_profile_flops(self.h, k, C.byref(fl)), "mhip_profile_flops")
+            out[self.lib.mhip_kernel_name(k).decode()] = {"id": k, "total_ms": ms.value, "launches": n.value,
+                                                          "flops": fl.value}
         return out
 
     def close(self):

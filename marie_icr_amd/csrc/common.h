@@ -192,3 +192,52 @@ int mhip_launch_posemb_bicubic(mhip_ctx* ctx, const float* tab, int gh, int gw, 
 int mhip_launch_convert_rows(mhip_ctx* ctx, int precision, const void* in, float* out, int rows, int D);
 int mhip_launch_unnest(mhip_ctx* ctx, int precision, const void* in, const void* coarse, void* out, int out_f32, int B,
                        int H, int W, int C, int nest);
+
+// ------------------------------------------------------------------ Pillow-exact resize (pil_resize.hip)
+size_t mhip_pil_resize_scratch_bytes(int sh, int sw, int dh, int dw, int filter);
+int mhip_launch_pil_resize_rgb(mhip_ctx* ctx, const uint8_t* src, int sh, int sw, size_t src_stride, uint8_t* dst, int dh,
+                               int dw, int filter, void* scratch);
+
+// ------------------------------------------------------------------ detector heads (det_ops.hip)
+void mhip_rpn_cell_anchors(const float sizes[5], const float ratios[3], float out[5][3][4]);
+struct RpnDesc {
+  const float* head[5];       // per level fp32 [images][H*W][16]: 3 objectness logits, 3 x 4 deltas, 1 pad
+  int H[5], W[5], stride[5];
+  float cell[5][3][4];
+  int images = 1;
+  int img_h = 0, img_w = 0;   // resized image size (proposal clip)
+  float nms_thr = 0.7f;
+  int post_topk = 1000;       // <= 1000
+  float* lvl_boxes = nullptr;   // scratch [images][5][1000][4]
+  float* lvl_scores = nullptr;  // scratch [images][5][1000]
+  int* lvl_counts = nullptr;    // scratch [images][5]
+  float* out_boxes = nullptr;   // [images][post_topk][4]
+  float* out_scores = nullptr;  // [images][post_topk]
+  int* out_counts = nullptr;    // [images]
+};
+int mhip_launch_rpn_proposals(mhip_ctx* ctx, const RpnDesc& d);
+struct RoiDesc {
+  const void* feat[4];   // p2..p5 NHWC T [images][H][W][C]
+  int H[4], W[4];
+  float scale[4];
+  const float* rois = nullptr;   // [images][max_rois][4]
+  const int* counts = nullptr;
+  int images = 1, max_rois = 1000, C = 256;
+  void* out = nullptr;           // [images][max_rois][49*C] T
+};
+int mhip_launch_roi_align(mhip_ctx* ctx, int precision, const RoiDesc& d);
+struct DetFinalDesc {
+  const float* head = nullptr;   // [images][max_rois][8]
+  const float* rois = nullptr;
+  const int* counts = nullptr;
+  int images = 1, max_rois = 1000;
+  int img_h = 0, img_w = 0, out_h = 0, out_w = 0;
+  float score_thr = 0.05f, nms_thr = 0.5f;
+  int max_det = 2000;
+  float* out_boxes = nullptr;    // [images][max_rois][4]
+  float* out_scores = nullptr;   // [images][max_rois]
+  int* out_count = nullptr;      // [images]
+};
+int mhip_launch_det_final(mhip_ctx* ctx, const DetFinalDesc& d);
+int mhip_launch_blackout(mhip_ctx* ctx, uint8_t* page, int H, int W, const int* boxes_dev, int n, int* changed_dev);
+int mhip_launch_subsample2(mhip_ctx* ctx, int precision, const void* in, void* out, int B, int H, int W, int C);

@@ -399,3 +399,42 @@ def make_image_u8(seed: int, n: int, h: int, w: int) -> np.ndarray:
             img += np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))[..., None] * amp
         out[i] = np.clip(img + 80, 0, 255).astype(np.uint8)
     return out
+
+
+DIT_VIT_PREFIX = "backbone.bottom_up.backbone."
+
+
+def make_dit_state(seed: int = 0, model: str = "base") -> Dict[str, np.ndarray]:
+    """Seeded weights for the whole DiT Mask R-CNN text detector under detectron2 checkpoint key names
+    (backbone.bottom_up.backbone.* = the BEiT module, backbone.fpn_*, proposal_generator.rpn_head.*, roi_heads.*).
+    Gains keep objectness / class scores spread out so top-k, NMS and the score threshold all cut somewhere non-trivial."""
+    dim, depth, heads = (768, 12, 12) if model == "base" else (1024, 24, 16)
+    st = {DIT_VIT_PREFIX + k: v for k, v in make_vit_state(seed, dim, depth, heads).items()}
+    rng = np.random.Generator(np.random.PCG64(seed + 60013))
+
+    def uni(shape, bound):
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    for lvl in (2, 3, 4, 5):
+        st[f"backbone.fpn_lateral{lvl}.weight"] = uni((256, dim, 1, 1), np.sqrt(3.0 / dim) * 0.5)
+        st[f"backbone.fpn_lateral{lvl}.bias"] = uni((256,), 0.1)
+        st[f"backbone.fpn_output{lvl}.weight"] = uni((256, 256, 3, 3), np.sqrt(3.0 / (256 * 9)))
+        st[f"backbone.fpn_output{lvl}.bias"] = uni((256,), 0.1)
+    r = "proposal_generator.rpn_head."
+    st[r + "conv.weight"] = uni((256, 256, 3, 3), np.sqrt(6.0 / (256 * 9)))
+    st[r + "conv.bias"] = uni((256,), 0.1)
+    st[r + "objectness_logits.weight"] = uni((3, 256, 1, 1), 4.0 * np.sqrt(3.0 / 256))
+    st[r + "objectness_logits.bias"] = uni((3,), 0.5)
+    st[r + "anchor_deltas.weight"] = uni((12, 256, 1, 1), 0.6 * np.sqrt(3.0 / 256))
+    st[r + "anchor_deltas.bias"] = uni((12,), 0.2)
+    h = "roi_heads.box_head."
+    st[h + "fc1.weight"] = uni((1024, 256 * 49), np.sqrt(6.0 / (256 * 49)))
+    st[h + "fc1.bias"] = uni((1024,), 0.1)
+    st[h + "fc2.weight"] = uni((1024, 1024), np.sqrt(6.0 / 1024))
+    st[h + "fc2.bias"] = uni((1024,), 0.1)
+    p = "roi_heads.box_predictor."
+    st[p + "cls_score.weight"] = uni((2, 1024), 3.0 * np.sqrt(3.0 / 1024))
+    st[p + "cls_score.bias"] = uni((2,), 0.2)
+    st[p + "bbox_pred.weight"] = uni((4, 1024), 2.0 * np.sqrt(3.0 / 1024))
+    st[p + "bbox_pred.bias"] = uni((4,), 0.2)
+    return st
