@@ -1,0 +1,245 @@
+"""``BoxProcessorUlimDit`` — the reference's DiT word-box processor surface over the MI355X detector.
+
+Mirrors marie/boxes/dit/ulim_dit_box_processor.py:358-832: same constructor arguments, ``psm_sparse_step`` /
+``psm_sparse`` (refinement passes with blackout, IoU > 0.1 de-duplication, the swapped-name aspect filter, lexsort,
+``lines_from_bboxes``) and ``extract_bounding_boxes`` (snippets cut from the ORIGINAL image, ``find_line_number``,
+(line, x) lexsort that leaves ``rect_line_numbers`` unpermuted — quirk Q1 in SURVEY.md section 8).  The detector, the
+blackout and the box/line geometry run in libmarie_hip.so; this file is the control flow between them.
+
+Not carried over: ``bbox_optimization`` (``crop_to_content_box``: OpenCV Otsu / GaussianBlur / morphology — off by default
+in the reference and in every caller on the hot path) raises NotImplementedError, as does ``resize_image``'s INTER_CUBIC
+shrink branch for inputs that are taller than MIN_SIZE_TEST but narrower (marie/utils/resize_image.py:53-61).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+
+from ._lib import PREC_F16, PREC_F32, Context, MarieHipError, check
+from .box_processor import PSMode
+from .dit import DitModel
+from .geometry import find_line_numbers, lines_from_bboxes, merge_boxes
+
+
+def resize_image(image: np.ndarray, desired_size, color=(255, 255, 255), keep_max_size: bool = False):
+    """The padding branches of marie/utils/resize_image.py:9-76 (``cv2.copyMakeBorder`` with a constant colour)."""
+    if image.shape[0] == desired_size[0] and image.shape[1] == desired_size[1]:
+        return image, (0, 0, image.shape[1], image.shape[0])
+    size = image.shape[:2]
+
+    def border(img, top, bottom, left, right):
+        out = np.empty((img.shape[0] + top + bottom, img.shape[1] + left + right, img.shape[2]), img.dtype)
+        out[...] = np.asarray(color, img.dtype)
+        out[top:top + img.shape[0], left:left + img.shape[1]] = img
+        return out
+
+    if keep_max_size:
+        h, w = size
+        dh, dw = desired_size
+        if w > dw and h < dh:
+            delta_h = max(0, desired_size[0] - size[0])
+            top, bottom = delta_h // 2, delta_h - (delta_h // 2)
+            image = border(image, top, bottom, 40, 40)
+            size = image.shape[:2]
+            return image, (40, top, size[1], size[0])
+    if size[0] > desired_size[0] or size[1] > desired_size[1]:
+        raise NotImplementedError("resize_image: the cv2.INTER_CUBIC shrink branch is not part of this build")
+    delta_w = max(0, desired_size[1] - size[1])
+    delta_h = max(0, desired_size[0] - size[0])
+    top, bottom = delta_h // 2, delta_h - (delta_h // 2)
+    left, right = delta_w // 2, delta_w - (delta_w // 2)
+    image = border(image, top, bottom, left, right)
+    return image, (left, top, size[1], size[0])
+
+
+def box_iou(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """torchvision.ops.box_iou on fp32 xyxy boxes."""
+    a = np.asarray(a, np.float32).reshape(-1, 4)
+    b = np.asarray(b, np.float32).reshape(-1, 4)
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = np.maximum(a[:, None, :2], b[None, :, :2])
+    rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+
+class BoxProcessorUlimDit:
+    """Drop-in for marie/boxes/dit/ulim_dit_box_processor.py:358."""
+
+    def __init__(self, work_dir: str = "/tmp/boxes", models_dir: Optional[str] = None, cuda: bool = False,
+                 refinement: bool = True, *, state: Optional[Dict[str, np.ndarray]] = None, model: str = "large",
+                 precision: str = "f16", device_id: int = 0, ctx: Optional[Context] = None, config=None):
+        if not cuda:
+            raise MarieHipError("BoxProcessorUlimDit here is the MI355X path; cuda=False has no implementation")
+        self.work_dir = work_dir
+        self.cuda = cuda
+        self.refinement = refinement
+        self.strict_box_segmentation = False
+        self.ctx = ctx or Context(device_id)
+        if state is None:
+            if models_dir is None:
+                raise ValueError("either `state` or `models_dir` is required")
+            import torch
+
+            # mask_rcnn_dit_prod.yaml:12 (MODEL.WEIGHTS, relative to the model zoo root)
+            path = os.path.join(models_dir, "unilm/dit/text_detection/tuned-4000-LARGE-05302024/model_0147999.pth")
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+            sd = sd.get("model", sd)
+            state = {k: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for k, v in sd.items()}
+        prec = {"f16": PREC_F16, "fp16": PREC_F16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
+        self.model = DitModel(self.ctx, state, model=model, precision=prec, config=config)
+        self.min_size_test = [self.model.cfg.min_size_test, self.model.cfg.min_size_test]
+
+    # -- device page helpers -------------------------------------------------------------------------------------
+    def _upload(self, image: np.ndarray):
+        import torch
+
+        return torch.from_numpy(np.ascontiguousarray(image)).cuda()
+
+    def _blackout(self, page_dev, boxes_xyxy) -> bool:
+        b = np.ascontiguousarray(np.asarray(boxes_xyxy, np.float32).reshape(-1, 4).astype(np.int32))   # int(x): truncation
+        changed = C.c_int(0)
+        h, w = page_dev.shape[:2]
+        check(self.ctx.h, self.ctx.lib.mhip_blackout_bboxes(self.ctx.h, C.c_void_p(page_dev.data_ptr()), h, w,
+                                                            b.ctypes.data_as(C.c_void_p), len(b), C.byref(changed)),
+              "mhip_blackout_bboxes")
+        return bool(changed.value)
+
+    # -- page segmentation ------------------------------------------------------------------------------------------
+    def psm_sparse_step(self, page_dev, shape, adj_x: int, adj_y: int):
+        """reference: ulim_dit_box_processor.py:424-497.  ``page_dev``: CUDA uint8 tensor (h, w, 3) BGR."""
+        import torch
+
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        (boxes, scores), = self.model.detect_device([page_dev.data_ptr()], shape[0], shape[1])
+        if len(boxes) == 0:
+            return [], [], []
+        bboxes = boxes
+        if adj_x != 0 or adj_y != 0:
+            bboxes[:, 0::2] -= np.float32(adj_x)
+            bboxes[:, 1::2] -= np.float32(adj_y)
+            bboxes[:, 0::2] = np.clip(bboxes[:, 0::2], 0, shape[1])
+            bboxes[:, 1::2] = np.clip(bboxes[:, 1::2], 0, shape[0])
+        keep = (bboxes[:, 2] - bboxes[:, 0] > 2) & (bboxes[:, 3] - bboxes[:, 1] > 2)
+        bboxes = bboxes[keep]
+        if len(bboxes) == 0:
+            return [], [], []
+        bboxes = np.array(merge_boxes(bboxes, 0.08))
+        # as in the reference, classes / scores keep the detector's length and order (they are not merged)
+        return bboxes, np.zeros((len(scores),), np.int64), scores
+
+    def psm_sparse(self, image: np.ndarray, bbox_optimization: Optional[bool] = False,
+                   bbox_context_aware: Optional[bool] = True, bbox_refinement: Optional[bool] = None,
+                   enable_visualization: Optional[bool] = False):
+        """reference: ulim_dit_box_processor.py:499-658."""
+        adj_x = adj_y = 0
+        if image.shape[0] < self.min_size_test[0] or image.shape[1] < self.min_size_test[1]:
+            image, coord = resize_image(image, (self.min_size_test[0], self.min_size_test[1]), keep_max_size=True)
+            adj_x, adj_y = coord[0], coord[1]
+        refinement = self.refinement if bbox_refinement is None else bbox_refinement
+        refinement_steps = 3 if refinement else 1
+        bboxes, classes, scores = [], [], []
+        page_dev = self._upload(image)           # the refinement image: boxes found so far are painted white on it
+        for i in range(refinement_steps):
+            bboxes_, classes_, scores_ = self.psm_sparse_step(page_dev, image.shape, adj_x, adj_y)
+            changed = self._blackout(page_dev, bboxes_) if len(bboxes_) else False
+            if i == 0:
+                bboxes.extend(bboxes_)
+                classes.extend(classes_)
+                scores.extend(scores_)
+                continue
+            if not changed:
+                break
+            if len(bboxes_) == 0:
+                break
+            ious = box_iou(np.asarray(bboxes, np.float32), np.asarray(bboxes_, np.float32))
+            tgt = np.unique(np.nonzero(ious > 0.1)[1])
+            bboxes_ = np.delete(bboxes_, tgt, axis=0)
+            classes_ = np.delete(classes_, tgt, axis=0)
+            scores_ = np.delete(scores_, tgt, axis=0)
+            bboxes.extend(bboxes_)
+            classes.extend(classes_)
+            scores.extend(scores_)
+        if bbox_optimization:
+            raise NotImplementedError("bbox_optimization (crop_to_content_box) is not part of this build")
+        bb, cc, sc = [], [], []
+        for box, cls, score in zip(bboxes, classes, scores):        # names swapped as in the reference (Q4): keeps wide boxes
+            h = box[2] - box[0]
+            w = box[3] - box[1]
+            if w / h < 2.5:
+                bb.append(box)
+                cc.append(cls)
+                sc.append(score)
+        bboxes, classes, scores = np.array(bb), np.array(cc), np.array(sc)
+        if len(bboxes) == 0:
+            return [], [], [], [], []
+        ind = np.lexsort((bboxes[:, 0], bboxes[:, 1]))
+        bboxes = bboxes[ind]
+        lines = lines_from_bboxes(image, bboxes)
+        return bboxes, classes, scores, lines, classes
+
+    def psm_word(self, image):
+        return self.psm_sparse(image)
+
+    def psm_line(self, image):
+        return self.psm_sparse(image)
+
+    def psm_raw_line(self, image):
+        return self.psm_sparse(image)
+
+    def psm_multiline(self, image):
+        return self.psm_sparse(image)
+
+    def extract_bounding_boxes(self, _id, key, img, psm=PSMode.SPARSE, bbox_optimization: Optional[bool] = False,
+                               bbox_context_aware: Optional[bool] = True, bbox_refinement: Optional[bool] = None
+                               ) -> Tuple[Any, Any, Any, Any, Any]:
+        """reference: ulim_dit_box_processor.py:676-832."""
+        if img is None:
+            raise Exception("Input image can't be empty")
+        if not isinstance(img, np.ndarray):
+            if hasattr(img, "convert"):      # PIL image -> BGR ndarray
+                img = np.array(img.convert("RGB"), dtype=np.uint8)[:, :, ::-1].copy()
+            else:
+                raise ValueError("Expected image in numpy format")
+        image = img.copy()
+        lines_bboxes = []
+        if psm == PSMode.SPARSE:
+            bboxes, polys, scores, lines_bboxes, classes = self.psm_sparse(image, bbox_optimization, bbox_context_aware,
+                                                                          bbox_refinement)
+        elif psm == PSMode.LINE:
+            bboxes, polys, scores, lines_bboxes, classes = self.psm_line(image)
+        elif psm == PSMode.MULTI_LINE:
+            bboxes, polys, scores, lines_bboxes, classes = self.psm_multiline(image)
+        elif psm == PSMode.RAW_LINE or psm == PSMode.WORD:
+            h, w = image.shape[:2]
+            return [[0, 0, w, h]], [image], [0], dict(), lines_bboxes
+        else:
+            raise Exception(f"PSM mode not supported : {psm}")
+        rect_from_poly, rect_line_numbers, fragments = [], [], []
+        if len(bboxes):
+            bi = np.asarray(bboxes).astype(np.int32)
+            xywh = np.stack([bi[:, 0], bi[:, 1], bi[:, 2] - bi[:, 0], bi[:, 3] - bi[:, 1]], axis=1)
+            numbers = find_line_numbers(lines_bboxes, xywh)
+            for i in range(len(bboxes)):
+                if classes[i] == 0:
+                    x0, y0, w, h = xywh[i]
+                    fragments.append(img[y0:y0 + h, x0:x0 + w:])
+                    rect_from_poly.append([x0, y0, w, h])
+                    rect_line_numbers.append(numbers[i])
+        if len(bboxes) > 0:
+            # the reference indexes rect_line_numbers by detection index here, so an (impossible on this model) non-text
+            # class would mis-align them; with one class the two index spaces coincide
+            aug = np.array([[b[0], b[1], b[2], b[3], rect_line_numbers[i]] for i, b in enumerate(bboxes)])
+            ind = np.lexsort((aug[:, 0], aug[:, 4]))
+            bboxes = bboxes[ind]
+            scores = scores[ind]
+            rect_from_poly = np.array(rect_from_poly)[ind]
+            fragments = [fragments[i] for i in ind]
+        fragments = [np.array(f, dtype=np.uint8) for f in fragments]
+        prediction_result = {"bboxes": bboxes, "polys": bboxes, "scores": scores, "heatmap": None}
+        return rect_from_poly, fragments, rect_line_numbers, prediction_result, lines_bboxes

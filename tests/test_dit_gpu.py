@@ -191,3 +191,28 @@ def test_detector_f16_and_batch(ctx, small_case):
     np.testing.assert_array_equal(res[0][0], out["boxes"])
     assert len(res[1][0]) > 0
     m.close()
+
+
+def test_box_processor_vs_oracle_pipeline(ctx, small_case):
+    """BoxProcessorUlimDit's control flow (refinement passes + blackout + merge_boxes + lines + line numbers) in fp32
+    against the same flow on the CPU oracle."""
+    from marie_icr_amd.box_processor import PSMode
+    from marie_icr_amd.dit_box_processor import BoxProcessorUlimDit
+    from oracle.dit_pipeline import OracleDitBoxProcessor
+
+    st, page, *_ = small_case
+    bp = BoxProcessorUlimDit(cuda=True, state=st, model="base", precision="f32", ctx=ctx, config=_config(ctx))
+    rects, frags, numbers, pred, lines = bp.extract_bounding_boxes("t", "k", page, PSMode.SPARSE)
+    o = OracleDitBoxProcessor(st, min_size=160, max_size=400)
+    orects, ofrags, onumbers, olines = o.extract_bounding_boxes(page)
+    assert len(rects) == len(frags) == len(numbers) and len(rects) > 5
+    assert abs(len(rects) - len(orects)) <= max(2, 0.05 * len(orects)), (len(rects), len(orects))
+    a = np.asarray(rects, np.float32); b = np.asarray(orects, np.float32)
+    a[:, 2:] += a[:, :2]; b[:, 2:] += b[:, :2]
+    assert (_iou_matrix(b, a).max(axis=1) >= 0.98).mean() >= 0.9
+    for r, f in zip(rects, frags):
+        np.testing.assert_array_equal(f, page[r[1]:r[1] + r[3], r[0]:r[0] + r[2]])
+    assert abs(len(lines) - len(olines)) <= 1
+    # RAW_LINE / WORD: the whole image is the single fragment
+    r2 = bp.extract_bounding_boxes("t", "k", page, PSMode.RAW_LINE)
+    assert r2[0] == [[0, 0, page.shape[1], page.shape[0]]] and r2[2] == [0]
