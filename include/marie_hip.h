@@ -309,6 +309,44 @@ int mhip_det_final_host(mhip_ctx* ctx, const float* head_host, const float* rois
 int mhip_blackout_bboxes(mhip_ctx* ctx, uint8_t* page_dev, int h, int w, const int32_t* boxes_xyxy_host, int n,
                          int* changed);
 
+/* ---- TrOCR recognizer (image encoder + text decoder + beam search) ------------------------------------------------------ */
+/* replaces: TrOcrProcessor's model path, marie/document/trocr_ocr_processor.py:116-180 (preprocess_image, get_text), with
+ * TrOCREncoder (marie/models/unilm/trocr/trocr_models.py:508-524), fairseq's TransformerDecoder (built :137-147) and
+ * TextRecognitionGenerator._generate (marie/models/unilm/trocr/generator.py:11-374).                                      */
+typedef struct mhip_trocr mhip_trocr;
+typedef struct mhip_trocr_config {
+  int enc_dim, enc_depth, enc_heads;            /* trocr_base: beit_base_patch16_384 = 768 / 12 / 12 (trocr_models.py:423-434) */
+  int dec_dim, dec_layers, dec_heads, dec_ffn;  /* 1024 / 12 / 16 / 4096                                                      */
+  int vocab;                                    /* len(target dictionary)                                                     */
+  int max_positions;                            /* decoder max_positions (512): embed_positions has max_positions + pad + 1 rows */
+  int beam;                                     /* 3 (trocr_ocr_processor.py:228)                                             */
+  int max_len_b;                                /* generation max_len_b (200); max_len = min(max_len_b, max_positions - 1)     */
+  int min_len;                                  /* 1                                                                          */
+  int pad, eos;                                 /* fairseq dictionary: 1, 2                                                   */
+  float embed_scale;                            /* 1.0 with RoBERTa's no_scale_embedding, else sqrt(dec_dim)                  */
+  int img_size;                                 /* 384                                                                        */
+} mhip_trocr_config;
+int mhip_trocr_default_config(int model /* 0 base, 1 large */, mhip_trocr_config* cfg);
+int mhip_trocr_max_len(const mhip_trocr_config* cfg);
+int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_config* cfg, mhip_trocr** out);
+int mhip_trocr_destroy(mhip_trocr* m);
+/* fairseq checkpoint keys: "encoder.deit.*" (timm VisionTransformer) and "decoder.*" (TransformerDecoder)                  */
+int mhip_trocr_set_tensor(mhip_trocr* m, const char* key, const float* data, const int64_t* shape, int ndim);
+int mhip_trocr_finalize(mhip_trocr* m);
+int mhip_trocr_alloc_arena(mhip_trocr* m);
+int mhip_trocr_arena(mhip_trocr* m, int which /* 0 encoder, 1 decoder */, void** arena_dev, size_t* bytes);
+size_t mhip_trocr_workspace_bytes(mhip_trocr* m, int n);
+/* n device crops u8 [img][img][3] -> best hypothesis per crop: tokens_out [n][max_len + 1] (eos included, pad-filled),
+ * lengths_out [n], scores_out [n] = length-normalised log-probability (the reference reports exp(score)).               */
+int mhip_trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int swap_rb, int32_t* tokens_out,
+                        int32_t* lengths_out, float* scores_out);
+/* host crops; optional parity taps: enc_tokens_out fp32 [n][577][enc_dim], step0_logits_out fp32 [n][vocab]               */
+int mhip_trocr_generate_host(mhip_trocr* m, const uint8_t* crops_host, int n, int swap_rb, int32_t* tokens_out,
+                             int32_t* lengths_out, float* scores_out, float* enc_tokens_out, float* step0_logits_out);
+/* fragments of any size (3 channels) inside one device buffer -> Pillow bicubic to img x img -> generate                    */
+int mhip_trocr_generate_fragments(mhip_trocr* m, const uint8_t* base_dev, const mhip_crop_desc* descs_host, int n,
+                                  int swap_rb, int32_t* tokens_out, int32_t* lengths_out, float* scores_out);
+
 /* ---- word-box / line geometry of the DiT box processor (host, pure functions; no ctx) --------------------------------- */
 /* replaces: merge_boxes, marie/utils/overlap.py:268-330 (find_overlap_horizontal(center_y_overlap=0.5) :106-183,
  * merge_bboxes_as_block :186-204).  xyxy fp32 [n][4] -> out_xyxy fp32 (capacity n rows), *n_out rows.       */

@@ -83,6 +83,18 @@ _SIGNATURES = (
     ("mhip_roi_align_host", _i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     ("mhip_det_final_host", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, _i, _vp, _vp, _vp]),
     ("mhip_blackout_bboxes", _i, [_vp, _vp, _i, _i, _vp, _i, C.POINTER(_i)]),
+    ("mhip_trocr_default_config", _i, [_i, _vp]),
+    ("mhip_trocr_max_len", _i, [_vp]),
+    ("mhip_trocr_create", _i, [_vp, _i, _vp, C.POINTER(_vp)]),
+    ("mhip_trocr_destroy", _i, [_vp]),
+    ("mhip_trocr_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
+    ("mhip_trocr_finalize", _i, [_vp]),
+    ("mhip_trocr_alloc_arena", _i, [_vp]),
+    ("mhip_trocr_arena", _i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
+    ("mhip_trocr_workspace_bytes", _sz, [_vp, _i]),
+    ("mhip_trocr_generate", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    ("mhip_trocr_generate_host", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_trocr_generate_fragments", _i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     ("mhip_merge_boxes", _i, [_vp, _i, _vp, C.POINTER(_i)]),
     ("mhip_line_merge", _i, [_vp, _i, _vp, C.POINTER(_i)]),
     ("mhip_find_line_numbers", _i, [_vp, _i, _vp, _i, _vp]),
@@ -123,6 +135,14 @@ class DitConfig(C.Structure):
     _fields_ = [("model", C.c_int), ("min_size_test", C.c_int), ("max_size_test", C.c_int),
                 ("detections_per_image", C.c_int), ("anchor_sizes", C.c_float * 5), ("aspect_ratios", C.c_float * 3),
                 ("rpn_nms_thresh", C.c_float), ("score_thresh", C.c_float), ("nms_thresh", C.c_float)]
+
+
+class TrocrConfig(C.Structure):
+    """mirror of mhip_trocr_config (include/marie_hip.h)"""
+    _fields_ = [("enc_dim", C.c_int), ("enc_depth", C.c_int), ("enc_heads", C.c_int), ("dec_dim", C.c_int),
+                ("dec_layers", C.c_int), ("dec_heads", C.c_int), ("dec_ffn", C.c_int), ("vocab", C.c_int),
+                ("max_positions", C.c_int), ("beam", C.c_int), ("max_len_b", C.c_int), ("min_len", C.c_int),
+                ("pad", C.c_int), ("eos", C.c_int), ("embed_scale", C.c_float), ("img_size", C.c_int)]
 
 
 class CropDesc(C.Structure):

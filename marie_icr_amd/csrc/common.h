@@ -23,7 +23,8 @@ enum MhipKernelId {
   MHIP_K_ATTN_FLASH = 8,  // ViT softmax attention: S^T = K Q^T -> online softmax -> O^T = V^T P^T on MFMA
   MHIP_K_VIT_OPS = 9,     // LayerNorm, patch extraction, token/map moves (HBM-bound)
   MHIP_K_DET_OPS = 10,    // detector heads: anchors/decode, top-k, NMS, ROIAlign
-  MHIP_K_COUNT = 11
+  MHIP_K_DEC_OPS = 11,    // text decoder steps: embedding, single-query attention over caches, beam candidates
+  MHIP_K_COUNT = 12
 };
 
 struct ProfSlot {
@@ -241,3 +242,32 @@ struct DetFinalDesc {
 int mhip_launch_det_final(mhip_ctx* ctx, const DetFinalDesc& d);
 int mhip_launch_blackout(mhip_ctx* ctx, uint8_t* page, int H, int W, const int* boxes_dev, int n, int* changed_dev);
 int mhip_launch_subsample2(mhip_ctx* ctx, int precision, const void* in, void* out, int B, int H, int W, int C);
+
+// ------------------------------------------------------------------ TrOCR decoder steps (trocr_ops.hip)
+int mhip_launch_layernorm2(mhip_ctx* ctx, int precision, const float* x, const float* g, const float* b, float* y_f32,
+                           void* y_t, int rows, int D, float eps);
+int mhip_launch_embed_step(mhip_ctx* ctx, int precision, const int* tokens, const void* emb, const float* pos_row, float scale,
+                           const float* g, const float* b, float* x, void* xt, int rows, int D, float eps);
+struct DecAttnDesc {
+  const void* q = nullptr;   // [groups*nq][ldq] T, pre-scaled
+  const void* k = nullptr;
+  const void* v = nullptr;
+  void* out = nullptr;       // [groups*nq][ldo] T
+  const int* anc = nullptr;  // self-attention: [rows][anc_ld] cache slot per past step (k/v laid out [step][slots][ldk])
+  int anc_ld = 0, slots = 0;
+  int kv_rows = 0;           // cross-attention: k/v rows per group
+  int ldq = 0, ldk = 0, ldo = 0;
+  int heads = 0, groups = 0, nq = 1, n_keys = 0;
+};
+int mhip_launch_decode_attention(mhip_ctx* ctx, int precision, const DecAttnDesc& d);
+struct BeamCandDesc {
+  const float* logits = nullptr;   // [bsz*beam][ld]
+  int ld = 0, vocab = 0, beam = 1, bsz = 0;
+  const float* cum = nullptr;      // [bsz*beam]
+  int step = 0, max_len = 0, min_len = 1, pad = 1, eos = 2;
+  float* cand_scores = nullptr;    // [bsz][2*beam]
+  int* cand_tokens = nullptr;
+  int* cand_beams = nullptr;
+};
+int mhip_launch_beam_candidates(mhip_ctx* ctx, const BeamCandDesc& d);
+int mhip_launch_ancestry(mhip_ctx* ctx, const int* anc_old, int* anc_new, const int* parent, int rows, int ld, int step);

@@ -23,7 +23,7 @@ int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...) {
 
 static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "lstm_rec",   "ctc_decode",
                                                  "image_ops",  "ccl",        "crop_batch", "attn",
-                                                 "attn_flash", "vit_ops",    "det_ops"};
+                                                 "attn_flash", "vit_ops",    "det_ops",    "dec_ops"};
 
 extern "C" int mhip_kernel_count(void) { return MHIP_K_COUNT; }
 extern "C" const char* mhip_kernel_name(int k) { return (k >= 0 && k < MHIP_K_COUNT) ? kKernelNames[k] : ""; }

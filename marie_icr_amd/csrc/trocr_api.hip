@@ -1,0 +1,464 @@
+// trocr_api.hip — the TrOCR recognizer (image encoder + autoregressive text decoder + beam search) behind the C ABI.
+//
+// Host-side counterpart of TrOcrProcessor's model path (marie/document/trocr_ocr_processor.py:116-180,251-367):
+//   preprocess_image: PIL bicubic resize of the fragment to 384 x 384, /255, (x - 0.5) / 0.5        (:116-125)
+//   TrOCREncoder.forward -> AdaptedVisionTransformer.forward_features (trocr_models.py:508-524; deit.py:105-146)
+//   TextRecognitionGenerator._generate (generator.py:11-374) over fairseq's TransformerDecoder
+//   (trocr_models.py:137-147,180-186): beam 3 (trocr_ocr_processor.py:228), max_len = min(200, max_positions - 1),
+//   cand_size = 2 * beam, length-normalised scores; the top hypothesis per fragment is returned.
+// fairseq is third-party and absent from the reference tree: decoder layer, incremental state, BeamSearch.step and
+// finalize_hypos follow fairseq's published v0.12 behaviour.
+//
+// MI355X shape of the problem: the encoder (577 tokens x 12 layers per fragment) is >= 85 % of the FLOPs and runs on
+// the ViT MFMA path; a decoder step is GEMMs with M = fragments x beams rows plus two HBM-bound attentions.  The
+// self-attention cache is never re-ordered: an ancestry table maps (hypothesis, past step) -> cache slot.
+#include <math.h>
+
+#include "vit_internal.h"
+
+struct mhip_trocr {
+  mhip_ctx* ctx = nullptr;
+  int precision = MHIP_PREC_F16;
+  mhip_trocr_config cfg{};
+  mhip_vit* vit = nullptr;
+  TensorStore store;
+  Arena arena;
+  bool ready = false;
+  size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
+};
+
+namespace {
+
+const char* kEncPrefix = "encoder.deit.";
+constexpr float DEC_LN_EPS = 1e-5f;
+
+std::string lay(int l, const char* s) { return "L" + std::to_string(l) + "." + s; }
+
+}  // namespace
+
+extern "C" int mhip_trocr_default_config(int model, mhip_trocr_config* c) {
+  if (!c || model < 0 || model > 1) return MHIP_EINVAL;
+  // trocr_base (beit_base_patch16_384) / trocr_large (beit_large_patch16_384): trocr_models.py:423-447
+  c->enc_dim = model ? 1024 : 768; c->enc_depth = model ? 24 : 12; c->enc_heads = model ? 16 : 12;
+  c->dec_dim = 1024; c->dec_layers = 12; c->dec_heads = 16; c->dec_ffn = 4096;
+  c->vocab = 50265;            // fairseq Dictionary over gpt2_with_mask.dict.txt (file not in the reference tree)
+  c->max_positions = 512;
+  c->beam = 3; c->max_len_b = 200; c->min_len = 1;
+  c->pad = 1; c->eos = 2;
+  c->embed_scale = 1.0f;       // RoBERTa arguments: no_scale_embedding
+  c->img_size = 384;
+  return MHIP_OK;
+}
+
+extern "C" int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_config* cfg, mhip_trocr** out) {
+  if (!ctx || !cfg || !out) return MHIP_EINVAL;
+  *out = nullptr;
+  if (precision != MHIP_PREC_F16 && precision != MHIP_PREC_F32) return mhip_fail(ctx, MHIP_EINVAL, "unknown precision %d", precision);
+  const mhip_trocr_config& c = *cfg;
+  if (c.dec_dim != c.dec_heads * 64 || c.dec_dim % 256 || c.dec_dim > 1024 || c.dec_ffn % 64 || c.dec_layers < 1 ||
+      c.vocab < 8 || c.beam < 1 || c.beam > 4 || c.img_size % 16 || c.max_len_b < 1 || c.max_positions < 2 ||
+      c.pad < 0 || c.eos < 0 || c.pad >= c.vocab || c.eos >= c.vocab)
+    return mhip_fail(ctx, MHIP_EINVAL, "trocr: unsupported configuration");
+  mhip_vit_config vc{};
+  vc.dim = c.enc_dim; vc.depth = c.enc_depth; vc.heads = c.enc_heads; vc.patch = 16;
+  vc.pos_h = vc.pos_w = c.img_size / 16;
+  vc.layer_scale = 0; vc.qkv_bias = 0; vc.final_norm = 1; vc.fpn = 0; vc.ln_eps = 1e-6f;
+  mhip_vit* vit = nullptr;
+  int rc = mhip_vit_create(ctx, precision, &vc, &vit);
+  if (rc) return rc;
+  mhip_trocr* m = new mhip_trocr();
+  m->ctx = ctx; m->precision = precision; m->cfg = c; m->vit = vit;
+  const size_t es = m->esz(), D = c.dec_dim, E = c.enc_dim, F = c.dec_ffn;
+  Arena& a = m->arena;
+  a.take("emb", (size_t)c.vocab * D * es);
+  a.take("out_w", (size_t)c.vocab * D * es);
+  a.take("pos", (size_t)(c.max_positions + c.pad + 1) * D * 4);
+  a.take("lne_g", D * 4); a.take("lne_b", D * 4);
+  for (int l = 0; l < c.dec_layers; ++l) {
+    for (const char* n : {"sa_q", "sa_k", "sa_v", "sa_o", "ca_q", "ca_o"}) { a.take(lay(l, n) + "_w", D * D * es); a.take(lay(l, n) + "_b", D * 4); }
+    for (const char* n : {"ca_k", "ca_v"}) { a.take(lay(l, n) + "_w", D * E * es); a.take(lay(l, n) + "_b", D * 4); }
+    a.take(lay(l, "fc1_w"), F * D * es); a.take(lay(l, "fc1_b"), F * 4);
+    a.take(lay(l, "fc2_w"), D * F * es); a.take(lay(l, "fc2_b"), D * 4);
+    for (const char* n : {"sa_ln", "ca_ln", "fin_ln"}) { a.take(lay(l, n) + "_g", D * 4); a.take(lay(l, n) + "_b", D * 4); }
+  }
+  *out = m;
+  return MHIP_OK;
+}
+
+extern "C" int mhip_trocr_destroy(mhip_trocr* m) {
+  if (!m) return MHIP_OK;
+  (void)hipStreamSynchronize(m->ctx->stream);
+  mhip_vit_destroy(m->vit);
+  m->arena.release();
+  delete m;
+  return MHIP_OK;
+}
+
+extern "C" int mhip_trocr_set_tensor(mhip_trocr* m, const char* key, const float* data, const int64_t* shape, int ndim) {
+  if (!m || !key) return MHIP_EINVAL;
+  std::string k(key);
+  if (k.rfind(kEncPrefix, 0) == 0) {
+    const std::string sub = k.substr(strlen(kEncPrefix));
+    if (sub.rfind("head.", 0) == 0 || sub.rfind("head_dist.", 0) == 0 || sub == "dist_token") return MHIP_OK;   // classifier heads: unused
+    return mhip_vit_set_tensor(m->vit, sub.c_str(), data, shape, ndim);
+  }
+  if (k == "decoder.version" || k == "encoder.version" || k.find("_float_tensor") != std::string::npos) return MHIP_OK;
+  if (k.rfind("decoder.", 0) != 0) return mhip_fail(m->ctx, MHIP_EINVAL, "unknown state_dict key %s", key);
+  m->ready = false;
+  return m->store.set(m->ctx, k, data, shape, ndim);
+}
+
+extern "C" int mhip_trocr_alloc_arena(mhip_trocr* m) {
+  if (!m) return MHIP_EINVAL;
+  int rc = m->arena.alloc(m->ctx);
+  if (rc) return rc;
+  if ((rc = mhip_vit_alloc_arena(m->vit))) return rc;
+  m->ready = true;
+  return MHIP_OK;
+}
+
+extern "C" int mhip_trocr_arena(mhip_trocr* m, int which, void** dev, size_t* bytes) {
+  if (!m || which < 0 || which > 1) return MHIP_EINVAL;
+  if (which == 0) return mhip_vit_arena(m->vit, dev, bytes);
+  if (dev) *dev = m->arena.dev;
+  if (bytes) *bytes = m->arena.bytes;
+  return MHIP_OK;
+}
+
+extern "C" int mhip_trocr_finalize(mhip_trocr* m) {
+  if (!m) return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  int rc = mhip_vit_finalize(m->vit);
+  if (rc) return rc;
+  const mhip_trocr_config& c = m->cfg;
+  const int prec = m->precision, D = c.dec_dim, E = c.enc_dim, F = c.dec_ffn;
+  Arena& a = m->arena;
+  const TensorStore& st = m->store;
+  a.begin_fill();
+  const HostTensor* emb = st.find(ctx, "decoder.embed_tokens.weight", {c.vocab, D});
+  const HostTensor* pos = st.find(ctx, "decoder.embed_positions.weight", {c.max_positions + c.pad + 1, D});
+  const HostTensor* lg = st.find(ctx, "decoder.layernorm_embedding.weight", {D});
+  const HostTensor* lb = st.find(ctx, "decoder.layernorm_embedding.bias", {D});
+  if (!emb || !pos || !lg || !lb) return MHIP_ESTATE;
+  Arena::put(prec, a.h("emb"), emb->data.data(), emb->numel());
+  if (st.has("decoder.output_projection.weight")) {
+    const HostTensor* ow = st.find(ctx, "decoder.output_projection.weight", {c.vocab, D});
+    if (!ow) return MHIP_ESTATE;
+    Arena::put(prec, a.h("out_w"), ow->data.data(), ow->numel());
+  } else {
+    Arena::put(prec, a.h("out_w"), emb->data.data(), emb->numel());   // share_decoder_input_output_embed
+  }
+  memcpy(a.h("pos"), pos->data.data(), pos->numel() * 4);
+  memcpy(a.h("lne_g"), lg->data.data(), D * 4);
+  memcpy(a.h("lne_b"), lb->data.data(), D * 4);
+  const float qscale = 0.125f;   // head_dim 64: MultiheadAttention scales q (bias included) by head_dim^-0.5
+  for (int l = 0; l < c.dec_layers; ++l) {
+    const std::string p = "decoder.layers." + std::to_string(l) + ".";
+    struct Lin { const char* name; std::string key; int out, in; float scale; };
+    const Lin lins[] = {{"sa_q", p + "self_attn.q_proj", D, D, qscale}, {"sa_k", p + "self_attn.k_proj", D, D, 1.f},
+                        {"sa_v", p + "self_attn.v_proj", D, D, 1.f},    {"sa_o", p + "self_attn.out_proj", D, D, 1.f},
+                        {"ca_q", p + "encoder_attn.q_proj", D, D, qscale}, {"ca_k", p + "encoder_attn.k_proj", D, E, 1.f},
+                        {"ca_v", p + "encoder_attn.v_proj", D, E, 1.f}, {"ca_o", p + "encoder_attn.out_proj", D, D, 1.f},
+                        {"fc1", p + "fc1", F, D, 1.f}, {"fc2", p + "fc2", D, F, 1.f}};
+    for (const Lin& L : lins) {
+      const HostTensor* w = st.find(ctx, L.key + ".weight", {L.out, L.in});
+      const HostTensor* b = st.find(ctx, L.key + ".bias", {L.out});
+      if (!w || !b) return MHIP_ESTATE;
+      if (L.scale != 1.f) {
+        std::vector<float> t(w->data);
+        for (float& v : t) v *= L.scale;
+        Arena::put(prec, a.h(lay(l, L.name) + "_w"), t.data(), t.size());
+        float* bb = (float*)a.h(lay(l, L.name) + "_b");
+        for (int i = 0; i < L.out; ++i) bb[i] = b->data[i] * L.scale;
+      } else {
+        Arena::put(prec, a.h(lay(l, L.name) + "_w"), w->data.data(), w->numel());
+        memcpy(a.h(lay(l, L.name) + "_b"), b->data.data(), (size_t)L.out * 4);
+      }
+    }
+    const std::pair<const char*, std::string> lns[] = {{"sa_ln", p + "self_attn_layer_norm"}, {"ca_ln", p + "encoder_attn_layer_norm"},
+                                                       {"fin_ln", p + "final_layer_norm"}};
+    for (const auto& ln : lns) {
+      const HostTensor* g = st.find(ctx, ln.second + ".weight", {D});
+      const HostTensor* b = st.find(ctx, ln.second + ".bias", {D});
+      if (!g || !b) return MHIP_ESTATE;
+      memcpy(a.h(lay(l, ln.first) + "_g"), g->data.data(), D * 4);
+      memcpy(a.h(lay(l, ln.first) + "_b"), b->data.data(), D * 4);
+    }
+  }
+  if ((rc = a.upload(ctx))) return rc;
+  m->ready = true;
+  m->store.t.clear();
+  return MHIP_OK;
+}
+
+static int trocr_max_len(const mhip_trocr_config& c) { return std::min(c.max_len_b, c.max_positions - 1); }
+
+extern "C" int mhip_trocr_max_len(const mhip_trocr_config* c) { return c ? trocr_max_len(*c) : MHIP_EINVAL; }
+
+static size_t trocr_ws_bytes(const mhip_trocr* m, int n) {
+  const mhip_trocr_config& c = m->cfg;
+  const size_t es = m->esz(), D = c.dec_dim, M = (size_t)n * c.beam, ML = trocr_max_len(c);
+  VitGeom vg;
+  vit_geometry(m->vit, c.img_size, c.img_size, &vg);
+  const size_t ldv = (c.vocab + 3) / 4 * 4;
+  size_t b = vit_workspace_bytes(m->vit, n, vg);
+  b += 2 * (size_t)c.dec_layers * n * vg.npad * D * es;               // cross K / V
+  b += 2 * (size_t)c.dec_layers * (ML + 1) * M * D * es;              // self K / V history
+  b += M * D * 4 + 3 * M * D * es + M * c.dec_ffn * es + M * ldv * 4; // x, xt, q, ao, hidden, logits
+  b += 2 * M * (ML + 2) * 4 + 4 * M * 4 + (size_t)n * 2 * c.beam * 12 + (size_t)vg.n_tok * c.enc_dim * 4;
+  return b + (1 << 16);
+}
+
+extern "C" size_t mhip_trocr_workspace_bytes(mhip_trocr* m, int n) { return (m && n > 0) ? trocr_ws_bytes(m, n) : 0; }
+
+// crops_dev: n images u8 [img][img][3].  tokens_out [n][max_len + 1] (the hypothesis without the leading eos, eos included,
+// padded with `pad`), lengths_out [n], scores_out [n] (length-normalised log-probability of the best hypothesis).
+static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int swap_rb, int32_t* tokens_out,
+                          int32_t* lengths_out, float* scores_out, float* enc_tokens_host, float* step0_logits_host) {
+  mhip_ctx* ctx = m->ctx;
+  if (!m->ready) return mhip_fail(ctx, MHIP_ESTATE, "trocr: weights not finalized");
+  if (n < 1) return mhip_fail(ctx, MHIP_EINVAL, "trocr: empty batch");
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const mhip_trocr_config& c = m->cfg;
+  const int prec = m->precision, D = c.dec_dim, E = c.enc_dim, F = c.dec_ffn, beam = c.beam, L = c.dec_layers;
+  const int K2 = 2 * beam, ML = trocr_max_len(c), M = n * beam;
+  const size_t es = m->esz();
+  const int ldv = (c.vocab + 3) / 4 * 4;
+  int rc = mhip_ensure_workspace(ctx, trocr_ws_bytes(m, n));
+  if (rc) return rc;
+  Carver ws(ctx->ws);
+  const Arena& a = m->arena;
+  // ---- encoder --------------------------------------------------------------------------------------------------
+  VitRun run;
+  if ((rc = vit_encode(m->vit, ws, crops_dev, n, c.img_size, c.img_size, c.img_size, c.img_size, swap_rb, &run))) return rc;
+  const VitGeom& vg = run.g;
+  if (enc_tokens_host) {
+    float* stage = ws.take<float>((size_t)vg.n_tok * E * 4);
+    for (int i = 0; i < n; ++i) {
+      if ((rc = mhip_launch_convert_rows(ctx, prec, run.tokens + (size_t)i * vg.npad * E * es, stage, vg.n_tok, E))) return rc;
+      MHIP_HIP(ctx, hipMemcpyAsync(enc_tokens_host + (size_t)i * vg.n_tok * E, stage, (size_t)vg.n_tok * E * 4, hipMemcpyDeviceToHost, ctx->stream));
+      MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  // ---- encoder keys / values of every decoder layer (static over the steps) -----------------------------------------
+  const size_t cross_l = (size_t)n * vg.npad * D * es;
+  char* ck = ws.take(L * cross_l);
+  char* cv = ws.take(L * cross_l);
+  for (int l = 0; l < L; ++l) {
+    if ((rc = mhip_gemm(ctx, prec, run.tokens, a.d(lay(l, "ca_k") + "_w"), (long long)n * vg.npad, D, E, nullptr, a.d<float>(lay(l, "ca_k") + "_b"), ck + l * cross_l, ACT_NONE, 0))) return rc;
+    if ((rc = mhip_gemm(ctx, prec, run.tokens, a.d(lay(l, "ca_v") + "_w"), (long long)n * vg.npad, D, E, nullptr, a.d<float>(lay(l, "ca_v") + "_b"), cv + l * cross_l, ACT_NONE, 0))) return rc;
+  }
+  // ---- decoder state ------------------------------------------------------------------------------------------------
+  const size_t hist_s = (size_t)M * D * es;                  // one step of one layer
+  char* hk = ws.take((size_t)L * (ML + 1) * hist_s);
+  char* hv = ws.take((size_t)L * (ML + 1) * hist_s);
+  float* x = ws.take<float>((size_t)M * D * 4);
+  char* xt = ws.take((size_t)M * D * es);
+  char* qb = ws.take((size_t)M * D * es);
+  char* ao = ws.take((size_t)M * D * es);
+  char* hid = ws.take((size_t)M * F * es);
+  float* logits = ws.take<float>((size_t)M * ldv * 4);
+  const int anc_ld = ML + 2;
+  int* anc[2] = {ws.take<int>((size_t)M * anc_ld * 4), ws.take<int>((size_t)M * anc_ld * 4)};
+  int* d_tok = ws.take<int>((size_t)M * 4);
+  int* d_parent = ws.take<int>((size_t)M * 4);
+  float* d_cum = ws.take<float>((size_t)M * 4);
+  float* d_cs = ws.take<float>((size_t)n * K2 * 4);
+  int* d_ct = ws.take<int>((size_t)n * K2 * 4);
+  int* d_cb = ws.take<int>((size_t)n * K2 * 4);
+
+  // host bookkeeping (TextRecognitionGenerator._generate without batch compaction: finished crops keep their rows)
+  std::vector<int> tokens((size_t)M * (ML + 2), c.pad), tokens_new(tokens.size());
+  std::vector<float> scores((size_t)M * (ML + 1), 0.f), scores_new(scores.size());
+  for (int r = 0; r < M; ++r) tokens[(size_t)r * (ML + 2)] = c.eos;
+  struct Hypo { float score; std::vector<int> toks; };
+  std::vector<std::vector<Hypo>> finalized(n);
+  std::vector<char> finished(n, 0), ignore((size_t)n * beam, 0);
+  int remaining = n;
+  std::vector<int> h_tok(M), h_parent(M), h_ct((size_t)n * K2), h_cb((size_t)n * K2);
+  std::vector<float> h_cum(M, 0.f), h_cs((size_t)n * K2);
+  for (int r = 0; r < M; ++r) { h_tok[r] = c.eos; h_parent[r] = r; }
+  {  // ancestry of step 0: every hypothesis reads its own slot
+    std::vector<int> a0((size_t)M * anc_ld, 0);
+    for (int r = 0; r < M; ++r) a0[(size_t)r * anc_ld] = r;
+    MHIP_HIP(ctx, hipMemcpyAsync(anc[0], a0.data(), a0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  int cur = 0;
+  for (int step = 0; step <= ML; ++step) {
+    MHIP_HIP(ctx, hipMemcpyAsync(d_tok, h_tok.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    MHIP_HIP(ctx, hipMemcpyAsync(d_cum, h_cum.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (step > 0) {
+      MHIP_HIP(ctx, hipMemcpyAsync(d_parent, h_parent.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+      if ((rc = mhip_launch_ancestry(ctx, anc[cur], anc[cur ^ 1], d_parent, M, anc_ld, step - 1))) return rc;
+      cur ^= 1;
+    }
+    // LearnedPositionalEmbedding, incremental: position = padding_idx + (step + 1)
+    const float* pos_row = a.d<float>("pos") + (size_t)(c.pad + step + 1) * D;
+    if ((rc = mhip_launch_embed_step(ctx, prec, d_tok, a.d("emb"), pos_row, c.embed_scale, a.d<float>("lne_g"), a.d<float>("lne_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
+    for (int l = 0; l < L; ++l) {
+      char* kl = hk + ((size_t)l * (ML + 1)) * hist_s;
+      char* vl = hv + ((size_t)l * (ML + 1)) * hist_s;
+      // self-attention over the hypothesis' own history (post-LN residual block)
+      if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "sa_q") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "sa_q") + "_b"), qb, ACT_NONE, 0))) return rc;
+      if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "sa_k") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "sa_k") + "_b"), kl + (size_t)step * hist_s, ACT_NONE, 0))) return rc;
+      if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "sa_v") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "sa_v") + "_b"), vl + (size_t)step * hist_s, ACT_NONE, 0))) return rc;
+      DecAttnDesc sa;
+      sa.q = qb; sa.k = kl; sa.v = vl; sa.out = ao; sa.anc = anc[cur]; sa.anc_ld = anc_ld; sa.slots = M;
+      sa.ldq = sa.ldk = sa.ldo = D; sa.heads = c.dec_heads; sa.groups = M; sa.nq = 1; sa.n_keys = step + 1;
+      if ((rc = mhip_launch_decode_attention(ctx, prec, sa))) return rc;
+      if ((rc = mhip_gemm(ctx, prec, ao, a.d(lay(l, "sa_o") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "sa_o") + "_b"), x, ACT_NONE, 1, x))) return rc;
+      if ((rc = mhip_launch_layernorm2(ctx, prec, x, a.d<float>(lay(l, "sa_ln") + "_g"), a.d<float>(lay(l, "sa_ln") + "_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
+      // attention over the crop's encoder tokens (keys / values shared by its beams)
+      if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "ca_q") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "ca_q") + "_b"), qb, ACT_NONE, 0))) return rc;
+      DecAttnDesc ca;
+      ca.q = qb; ca.k = ck + l * cross_l; ca.v = cv + l * cross_l; ca.out = ao; ca.kv_rows = vg.npad;
+      ca.ldq = ca.ldk = ca.ldo = D; ca.heads = c.dec_heads; ca.groups = n; ca.nq = beam; ca.n_keys = vg.n_tok;
+      if ((rc = mhip_launch_decode_attention(ctx, prec, ca))) return rc;
+      if ((rc = mhip_gemm(ctx, prec, ao, a.d(lay(l, "ca_o") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "ca_o") + "_b"), x, ACT_NONE, 1, x))) return rc;
+      if ((rc = mhip_launch_layernorm2(ctx, prec, x, a.d<float>(lay(l, "ca_ln") + "_g"), a.d<float>(lay(l, "ca_ln") + "_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
+      // feed-forward
+      if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "fc1_w")), M, F, D, nullptr, a.d<float>(lay(l, "fc1_b")), hid, ACT_GELU, 0))) return rc;
+      if ((rc = mhip_gemm(ctx, prec, hid, a.d(lay(l, "fc2_w")), M, D, F, nullptr, a.d<float>(lay(l, "fc2_b")), x, ACT_NONE, 1, x))) return rc;
+      if ((rc = mhip_launch_layernorm2(ctx, prec, x, a.d<float>(lay(l, "fin_ln") + "_g"), a.d<float>(lay(l, "fin_ln") + "_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
+    }
+    if ((rc = mhip_gemm(ctx, prec, xt, a.d("out_w"), M, c.vocab, D, nullptr, nullptr, logits, ACT_NONE, 1, nullptr, ldv))) return rc;
+    if (step == 0 && step0_logits_host) {
+      for (int i = 0; i < n; ++i)
+        MHIP_HIP(ctx, hipMemcpyAsync(step0_logits_host + (size_t)i * c.vocab, logits + (size_t)i * beam * ldv, (size_t)c.vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    BeamCandDesc bc;
+    bc.logits = logits; bc.ld = ldv; bc.vocab = c.vocab; bc.beam = beam; bc.bsz = n; bc.cum = d_cum; bc.step = step;
+    bc.max_len = ML; bc.min_len = c.min_len; bc.pad = c.pad; bc.eos = c.eos;
+    bc.cand_scores = d_cs; bc.cand_tokens = d_ct; bc.cand_beams = d_cb;
+    if ((rc = mhip_launch_beam_candidates(ctx, bc))) return rc;
+    MHIP_HIP(ctx, hipMemcpyAsync(h_cs.data(), d_cs, (size_t)n * K2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MHIP_HIP(ctx, hipMemcpyAsync(h_ct.data(), d_ct, (size_t)n * K2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MHIP_HIP(ctx, hipMemcpyAsync(h_cb.data(), d_cb, (size_t)n * K2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // ---- generator bookkeeping for this step ----------------------------------------------------------------------
+    tokens_new = tokens;
+    scores_new = scores;
+    for (int s = 0; s < n; ++s) {
+      if (finished[s]) {
+        for (int b = 0; b < beam; ++b) { h_parent[s * beam + b] = s * beam + b; h_tok[s * beam + b] = c.eos; }
+        continue;
+      }
+      const float* cs = &h_cs[(size_t)s * K2];
+      const int* ct = &h_ct[(size_t)s * K2];
+      const int* cb = &h_cb[(size_t)s * K2];
+      bool eos_mask[8];
+      for (int j = 0; j < K2; ++j) eos_mask[j] = ct[j] == c.eos && cs[j] != -INFINITY;
+      for (int j = 0; j < beam; ++j)
+        if (ignore[(size_t)s * beam + j]) eos_mask[j] = false;
+      // finalize_hypos: eos candidates among the first `beam`
+      for (int j = 0; j < beam; ++j) {
+        if (!eos_mask[j]) continue;
+        const int src = s * beam + cb[j];
+        if ((int)finalized[s].size() < beam) {
+          Hypo h;
+          h.toks.assign(tokens.begin() + (size_t)src * (ML + 2) + 1, tokens.begin() + (size_t)src * (ML + 2) + 1 + step);
+          h.toks.push_back(c.eos);
+          h.score = cs[j] / (float)(step + 1);          // normalize_scores, len_penalty 1
+          finalized[s].push_back(std::move(h));
+        }
+      }
+      if ((int)finalized[s].size() == beam || step == ML) {
+        if (!finalized[s].empty() || step == ML) {
+          finished[s] = 1;
+          --remaining;
+          for (int b = 0; b < beam; ++b) { h_parent[s * beam + b] = s * beam + b; h_tok[s * beam + b] = c.eos; }
+          continue;
+        }
+      }
+      // active hypotheses: the `beam` best candidates that are not finished ones
+      for (int j = 0; j < beam; ++j) eos_mask[j] = eos_mask[j] || ignore[(size_t)s * beam + j];
+      int order[8], nact = 0;
+      for (int j = 0; j < K2 && nact < beam; ++j)
+        if (!eos_mask[j]) order[nact++] = j;
+      int nign = 0;
+      for (int j = 0; j < K2 && nact + nign < beam; ++j)
+        if (eos_mask[j]) order[nact + nign++] = j;      // fewer than `beam` live candidates: the rest are ignored slots
+      for (int b = 0; b < beam; ++b) {
+        const int j = order[b], row = s * beam + b, src = s * beam + cb[j];
+        ignore[(size_t)s * beam + b] = b >= nact;
+        std::copy(tokens.begin() + (size_t)src * (ML + 2), tokens.begin() + (size_t)src * (ML + 2) + step + 1, tokens_new.begin() + (size_t)row * (ML + 2));
+        tokens_new[(size_t)row * (ML + 2) + step + 1] = ct[j];
+        if (step > 0)
+          std::copy(scores.begin() + (size_t)src * (ML + 1), scores.begin() + (size_t)src * (ML + 1) + step, scores_new.begin() + (size_t)row * (ML + 1));
+        scores_new[(size_t)row * (ML + 1) + step] = cs[j];
+        h_parent[row] = src;
+        h_tok[row] = ct[j];
+        h_cum[row] = cs[j];
+      }
+    }
+    tokens.swap(tokens_new);
+    scores.swap(scores_new);
+    if (remaining == 0) break;
+  }
+  // best hypothesis per crop: highest score, first finalized wins ties (torch.sort(descending) on the score list)
+  for (int s = 0; s < n; ++s) {
+    int best = -1;
+    for (int j = 0; j < (int)finalized[s].size(); ++j)
+      if (best < 0 || finalized[s][j].score > finalized[s][best].score) best = j;
+    int32_t* to = tokens_out + (size_t)s * (ML + 1);
+    for (int t = 0; t <= ML; ++t) to[t] = c.pad;
+    if (best < 0) { lengths_out[s] = 0; scores_out[s] = -INFINITY; continue; }
+    const Hypo& h = finalized[s][best];
+    for (size_t t = 0; t < h.toks.size() && t < (size_t)ML + 1; ++t) to[t] = h.toks[t];
+    lengths_out[s] = (int32_t)h.toks.size();
+    scores_out[s] = h.score;
+  }
+  return MHIP_OK;
+}
+
+extern "C" int mhip_trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int swap_rb, int32_t* tokens_out,
+                                   int32_t* lengths_out, float* scores_out) {
+  if (!m || !crops_dev || !tokens_out || !lengths_out || !scores_out) return MHIP_EINVAL;
+  return trocr_generate(m, crops_dev, n, swap_rb, tokens_out, lengths_out, scores_out, nullptr, nullptr);
+}
+
+extern "C" int mhip_trocr_generate_host(mhip_trocr* m, const uint8_t* crops_host, int n, int swap_rb, int32_t* tokens_out,
+                                        int32_t* lengths_out, float* scores_out, float* enc_tokens_out,
+                                        float* step0_logits_out) {
+  if (!m || !crops_host || !tokens_out || !lengths_out || !scores_out || n < 1) return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t nb = (size_t)n * m->cfg.img_size * m->cfg.img_size * 3;
+  uint8_t* dev = nullptr;
+  MHIP_HIP(ctx, hipMalloc((void**)&dev, nb));
+  hipError_t e = hipMemcpy(dev, crops_host, nb, hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? MHIP_OK : mhip_fail(ctx, MHIP_EHIP, "crop upload: %s", hipGetErrorString(e));
+  if (!rc) rc = trocr_generate(m, dev, n, swap_rb, tokens_out, lengths_out, scores_out, enc_tokens_out, step0_logits_out);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dev);
+  return rc;
+}
+
+// Fragments of any size (u8, 3 channels, rows of row_stride bytes at base_dev + src_offset) -> Pillow bicubic resize to
+// img x img (aspect ratio not preserved, as preprocess_image does) -> generate.
+extern "C" int mhip_trocr_generate_fragments(mhip_trocr* m, const uint8_t* base_dev, const mhip_crop_desc* descs_host, int n,
+                                             int swap_rb, int32_t* tokens_out, int32_t* lengths_out, float* scores_out) {
+  if (!m || !base_dev || !descs_host || !tokens_out || !lengths_out || !scores_out || n < 1) return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const int S = m->cfg.img_size;
+  size_t scratch = 0;
+  for (int i = 0; i < n; ++i) {
+    if (descs_host[i].channels != 3 || descs_host[i].h < 1 || descs_host[i].w < 1) return mhip_fail(ctx, MHIP_EINVAL, "trocr: fragment %d must be h x w x 3", i);
+    scratch = std::max(scratch, mhip_pil_resize_scratch_bytes(descs_host[i].h, descs_host[i].w, S, S, MHIP_PIL_BICUBIC));
+  }
+  uint8_t* crops = nullptr;
+  void* sc = nullptr;
+  MHIP_HIP(ctx, hipMalloc((void**)&crops, (size_t)n * S * S * 3));
+  if (hipMalloc(&sc, scratch) != hipSuccess) { (void)hipFree(crops); return mhip_fail(ctx, MHIP_ENOMEM, "trocr: resize scratch"); }
+  int rc = MHIP_OK;
+  for (int i = 0; i < n && !rc; ++i)
+    rc = mhip_launch_pil_resize_rgb(ctx, base_dev + descs_host[i].src_offset, descs_host[i].h, descs_host[i].w,
+                                    (size_t)descs_host[i].row_stride, crops + (size_t)i * S * S * 3, S, S, MHIP_PIL_BICUBIC, sc);
+  if (!rc) rc = trocr_generate(m, crops, n, swap_rb, tokens_out, lengths_out, scores_out, nullptr, nullptr);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(sc);
+  (void)hipFree(crops);
+  return rc;
+}

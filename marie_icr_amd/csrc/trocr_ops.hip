@@ -1,0 +1,350 @@
+// trocr_ops.hip — the per-step pieces of the TrOCR text decoder that are not GEMMs.
+//
+// The decoder is fairseq's TransformerDecoder (third-party; built at marie/models/unilm/trocr/trocr_models.py:137-147,
+// 180-186 from RoBERTa arguments: post-LayerNorm layers, learned positions, layernorm_embedding, tied output projection)
+// driven one token at a time by TextRecognitionGenerator._generate (marie/models/unilm/trocr/generator.py:11-374).
+//   embed_step        embed_tokens[token] * embed_scale + embed_positions[pad + 1 + step] -> layernorm_embedding
+//   layernorm2        post-LN after a residual GEMM: fp32 stream and the GEMM operand copy in one pass
+//   decode_attention  one query per hypothesis against (a) its own key/value history, addressed through an ancestry
+//                     table so that beam re-ordering never copies the cache, (b) the crop's 577 encoder keys/values,
+//                     shared by the beams of the crop.  HBM-bound: every K/V element is read once per step.
+//   beam_candidates   log_softmax over the vocabulary + cumulative score + the generator's pad / eos masks, then the
+//                     2 x beam best (hypothesis, token) pairs per crop (BeamSearch.step)
+#include <math.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// one wave per row: y = LN(x) (two-pass), written as fp32 (may alias x) and as T
+template <typename T>
+__device__ __forceinline__ void ln_row(const float* xr, const float* g, const float* b, float* yo, T* to, int D, float eps,
+                                       int lane, float4v v[4]) {
+  const int nv = D >> 8;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < nv)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < nv) {
+      const int c = (i * 64 + lane) * 4;
+      const float4v gg = *(const float4v*)(g + c), bb = *(const float4v*)(b + c);
+      float4v y;
+      T o4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { y[k] = (v[i][k] - mean) * rstd * gg[k] + bb[k]; o4[k] = (T)y[k]; }
+      if (yo) *(float4v*)(yo + c) = y;
+      if (sizeof(T) == 2) *(uint64_t*)(to + c) = *(uint64_t*)o4;
+      else *(float4v*)(to + c) = *(float4v*)o4;
+    }
+  (void)xr;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ b, float* yo, T* __restrict__ to,
+                                                         int rows, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float4v v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < (D >> 8)) v[i] = *(const float4v*)(x + (size_t)row * D + (i * 64 + lane) * 4);
+  ln_row<T>(nullptr, g, b, yo ? yo + (size_t)row * D : nullptr, to + (size_t)row * D, D, eps, lane, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_step_kernel(const int* __restrict__ tokens, const T* __restrict__ emb,
+                                                         const float* __restrict__ pos_row, float scale,
+                                                         const float* __restrict__ g, const float* __restrict__ b, float* xo,
+                                                         T* __restrict__ to, int rows, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const T* e = emb + (size_t)tokens[row] * D;
+  float4v v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < (D >> 8)) {
+      const int c = (i * 64 + lane) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = (float)e[c + k] * scale + pos_row[c + k];
+    }
+  ln_row<T>(nullptr, g, b, xo + (size_t)row * D, to + (size_t)row * D, D, eps, lane, v);
+}
+
+// ---- decode attention ---------------------------------------------------------------------------------------------------
+// grid (heads, groups); a group = NQ consecutive query rows that share one key/value set.
+//   self-attention : NQ = 1, group = hypothesis row; key s lives at kbase + ((size_t)s * slots + anc[row*anc_ld + s]) * ld
+//   cross-attention: NQ = beam, group = crop;        key s lives at kbase + ((size_t)group * kv_rows + s) * ld
+struct DecAttnArgs {
+  const void* q;     // [rows][ldq] T, pre-scaled by head_dim^-0.5
+  const void* k;
+  const void* v;
+  void* out;         // [rows][ldo] T
+  const int* anc;    // self: [rows][anc_ld] slot of each past step; nullptr for cross
+  int anc_ld, slots;
+  int kv_rows;       // cross: rows per group in k / v
+  int ldq, ldk, ldo;
+  int n_keys, nq;
+};
+
+constexpr int DA_MAXK = 640, DA_MAXQ = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
+  __shared__ float sq[DA_MAXQ][64];
+  __shared__ float sp[DA_MAXQ][DA_MAXK];
+  __shared__ float red[DA_MAXQ][4][64];
+  __shared__ float smax[DA_MAXQ], ssum[DA_MAXQ];
+  const int h = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x;
+  const int row0 = grp * p.nq;
+  for (int e = tid; e < p.nq * 64; e += 256) sq[e >> 6][e & 63] = (float)((const T*)p.q)[(size_t)(row0 + (e >> 6)) * p.ldq + h * 64 + (e & 63)];
+  __syncthreads();
+  auto key_row = [&](int s) -> size_t {
+    return p.anc ? ((size_t)s * p.slots + p.anc[(size_t)row0 * p.anc_ld + s]) : ((size_t)grp * p.kv_rows + s);
+  };
+  // scores
+  for (int s = tid; s < p.n_keys; s += 256) {
+    const T* kr = (const T*)p.k + key_row(s) * p.ldk + h * 64;
+    float acc[DA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < 64; d += 8) {
+      float kv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kv[j] = (float)kr[d + j];
+#pragma unroll
+      for (int qi = 0; qi < DA_MAXQ; ++qi)
+        if (qi < p.nq)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[qi] += sq[qi][d + j] * kv[j];
+    }
+    for (int qi = 0; qi < p.nq; ++qi) sp[qi][s] = acc[qi];
+  }
+  __syncthreads();
+  // softmax per query: wave qi handles query qi
+  {
+    const int qi = tid >> 6, lane = tid & 63;
+    if (qi < p.nq) {
+      float m = -INFINITY;
+      for (int s = lane; s < p.n_keys; s += 64) m = fmaxf(m, sp[qi][s]);
+#pragma unroll
+      for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float sum = 0.f;
+      for (int s = lane; s < p.n_keys; s += 64) { const float e = expf(sp[qi][s] - m); sp[qi][s] = e; sum += e; }
+      sum = wave_sum(sum);
+      if (lane == 0) { smax[qi] = m; ssum[qi] = sum; }
+    }
+  }
+  __syncthreads();
+  // weighted values: thread (d = tid & 63, part = tid >> 6) sums keys = part mod 4
+  {
+    const int d = tid & 63, part = tid >> 6;
+    float acc[DA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = part; s < p.n_keys; s += 4) {
+      const float vv = (float)((const T*)p.v)[key_row(s) * p.ldk + h * 64 + d];
+#pragma unroll
+      for (int qi = 0; qi < DA_MAXQ; ++qi)
+        if (qi < p.nq) acc[qi] += sp[qi][s] * vv;
+    }
+    for (int qi = 0; qi < p.nq; ++qi) red[qi][part][d] = acc[qi];
+  }
+  __syncthreads();
+  for (int e = tid; e < p.nq * 64; e += 256) {
+    const int qi = e >> 6, d = e & 63;
+    const float o = (red[qi][0][d] + red[qi][1][d]) + (red[qi][2][d] + red[qi][3][d]);
+    ((T*)p.out)[(size_t)(row0 + qi) * p.ldo + h * 64 + d] = (T)(o / ssum[qi]);
+  }
+}
+
+// ---- beam candidates ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned okey(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float okey_inv(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+struct CandArgs {
+  const float* logits;    // [bsz*beam][ld]
+  int ld, vocab, beam;
+  const float* cum;       // [bsz*beam] cumulative score of each hypothesis (scores[:, step-1]); unused at step 0
+  int step, max_len, min_len;
+  int pad, eos;
+  float* cand_scores;     // [bsz][2*beam]
+  int* cand_tokens;       // [bsz][2*beam]
+  int* cand_beams;        // [bsz][2*beam]
+};
+
+constexpr int CAND_T = 1024, CAND_K = 8;   // per-thread shortlist
+
+// one workgroup per crop
+__global__ __launch_bounds__(CAND_T) void beam_candidates_kernel(CandArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64* keys = (u64*)smem;                 // CAND_T * CAND_K
+  __shared__ float rmax[8], rlse[8];
+  __shared__ float wred[16];
+  const int sample = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nb = p.step == 0 ? 1 : p.beam;          // step 0: all beams are identical, only the first one competes
+  const int K = 2 * p.beam;
+  // log-sum-exp per hypothesis row
+  for (int b = 0; b < nb; ++b) {
+    const float* row = p.logits + (size_t)(sample * p.beam + b) * p.ld;
+    float m = -INFINITY;
+    for (int i = tid; i < p.vocab; i += CAND_T) m = fmaxf(m, row[i]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) wred[wv] = m;
+    __syncthreads();
+    if (tid == 0) { float mm = wred[0]; for (int w = 1; w < 16; ++w) mm = fmaxf(mm, wred[w]); rmax[b] = mm; }
+    __syncthreads();
+    m = rmax[b];
+    float s = 0.f;
+    for (int i = tid; i < p.vocab; i += CAND_T) s += expf(row[i] - m);
+    s = wave_sum(s);
+    if (lane == 0) wred[wv] = s;
+    __syncthreads();
+    if (tid == 0) { float ss = 0.f; for (int w = 0; w < 16; ++w) ss += wred[w]; rlse[b] = m + logf(ss); }
+    __syncthreads();
+  }
+  // per-thread shortlist of the K best (score, flat index) pairs; flat index = b * vocab + token
+  u64 best[CAND_K];
+#pragma unroll
+  for (int j = 0; j < CAND_K; ++j) best[j] = 0;
+  for (int b = 0; b < nb; ++b) {
+    const float* row = p.logits + (size_t)(sample * p.beam + b) * p.ld;
+    const float base = (p.step == 0 ? 0.f : p.cum[sample * p.beam + b]);
+    for (int i = tid; i < p.vocab; i += CAND_T) {
+      float lp = row[i] - rlse[b];
+      if (lp != lp) lp = -INFINITY;
+      if (i == p.pad) lp = -INFINITY;
+      if (p.step >= p.max_len && i != p.eos) lp = -INFINITY;
+      if (p.step < p.min_len && i == p.eos) lp = -INFINITY;
+      const float sc = lp + base;
+      const u64 key = ((u64)okey(sc) << 32) | (u64)(0xffffffffu - (unsigned)(b * p.vocab + i));
+      if (key > best[K - 1]) {
+        best[K - 1] = key;
+#pragma unroll
+        for (int j = CAND_K - 1; j > 0; --j)
+          if (j < K && best[j] > best[j - 1]) { const u64 t = best[j]; best[j] = best[j - 1]; best[j - 1] = t; }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CAND_K; ++j) keys[tid * CAND_K + j] = j < K ? best[j] : 0;
+  // bitonic sort (descending) of CAND_T * CAND_K keys
+  const int n = CAND_T * CAND_K;
+  for (int k = 2; k <= n; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < n; i += CAND_T) {
+        const int l = i ^ j;
+        if (l > i) {
+          const u64 x = keys[i], y = keys[l];
+          const bool up = (i & k) == 0;
+          if (up ? (x < y) : (x > y)) { keys[i] = y; keys[l] = x; }
+        }
+      }
+    }
+  __syncthreads();
+  if (tid < K) {
+    const u64 c = keys[tid];
+    const unsigned flat = 0xffffffffu - (unsigned)(c & 0xffffffffu);
+    p.cand_scores[sample * K + tid] = okey_inv((unsigned)(c >> 32));
+    p.cand_tokens[sample * K + tid] = (int)(flat % (unsigned)p.vocab);
+    p.cand_beams[sample * K + tid] = (int)(flat / (unsigned)p.vocab);
+  }
+}
+
+// anc_new[r][0..step] = anc_old[parent[r]][0..step]; anc_new[r][step+1] = r
+__global__ void ancestry_kernel(const int* __restrict__ anc_old, int* __restrict__ anc_new, const int* __restrict__ parent,
+                                int rows, int ld, int step) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * (step + 2)) return;
+  const int r = e / (step + 2), s = e - r * (step + 2);
+  anc_new[(size_t)r * ld + s] = s == step + 1 ? r : anc_old[(size_t)parent[r] * ld + s];
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH(ctx, what)                                                                              \
+  do {                                                                                                       \
+    hipError_t _e = hipGetLastError();                                                                       \
+    if (_e != hipSuccess) return mhip_fail((ctx), MHIP_EHIP, what " launch: %s", hipGetErrorString(_e));    \
+  } while (0)
+
+int mhip_launch_layernorm2(mhip_ctx* ctx, int precision, const float* x, const float* g, const float* b, float* y_f32,
+                           void* y_t, int rows, int D, float eps) {
+  if (D % 256 != 0 || D > 1024 || rows <= 0) return mhip_fail(ctx, MHIP_EINVAL, "layernorm2: D=%d rows=%d", D, rows);
+  dim3 grid((rows + 3) / 4), block(256);
+  if (precision == MHIP_PREC_F16) PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(layernorm2_kernel<_Float16>, grid, block, 0, ctx->stream, x, g, b, y_f32, (_Float16*)y_t, rows, D, eps));
+  else PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(layernorm2_kernel<float>, grid, block, 0, ctx->stream, x, g, b, y_f32, (float*)y_t, rows, D, eps));
+  CHECK_LAUNCH(ctx, "layernorm2");
+  return 0;
+}
+
+int mhip_launch_embed_step(mhip_ctx* ctx, int precision, const int* tokens, const void* emb, const float* pos_row, float scale,
+                           const float* g, const float* b, float* x, void* xt, int rows, int D, float eps) {
+  if (D % 256 != 0 || D > 1024 || rows <= 0) return mhip_fail(ctx, MHIP_EINVAL, "embed_step: D=%d rows=%d", D, rows);
+  dim3 grid((rows + 3) / 4), block(256);
+  if (precision == MHIP_PREC_F16) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(embed_step_kernel<_Float16>, grid, block, 0, ctx->stream, tokens, (const _Float16*)emb, pos_row, scale, g, b, x, (_Float16*)xt, rows, D, eps));
+  else PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(embed_step_kernel<float>, grid, block, 0, ctx->stream, tokens, (const float*)emb, pos_row, scale, g, b, x, (float*)xt, rows, D, eps));
+  CHECK_LAUNCH(ctx, "embed_step");
+  return 0;
+}
+
+int mhip_launch_decode_attention(mhip_ctx* ctx, int precision, const DecAttnDesc& d) {
+  if (d.n_keys < 1 || d.n_keys > DA_MAXK || d.nq < 1 || d.nq > DA_MAXQ || d.heads < 1 || d.groups < 1)
+    return mhip_fail(ctx, MHIP_EINVAL, "decode_attention: n_keys %d nq %d", d.n_keys, d.nq);
+  DecAttnArgs a;
+  a.q = d.q; a.k = d.k; a.v = d.v; a.out = d.out; a.anc = d.anc; a.anc_ld = d.anc_ld; a.slots = d.slots;
+  a.kv_rows = d.kv_rows; a.ldq = d.ldq; a.ldk = d.ldk; a.ldo = d.ldo; a.n_keys = d.n_keys; a.nq = d.nq;
+  dim3 grid(d.heads, d.groups), block(256);
+  if (precision == MHIP_PREC_F16) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(decode_attn_kernel<_Float16>, grid, block, 0, ctx->stream, a));
+  else PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(decode_attn_kernel<float>, grid, block, 0, ctx->stream, a));
+  CHECK_LAUNCH(ctx, "decode_attention");
+  return 0;
+}
+
+int mhip_launch_beam_candidates(mhip_ctx* ctx, const BeamCandDesc& d) {
+  if (d.beam < 1 || d.beam > 4 || d.vocab < 2 * d.beam) return mhip_fail(ctx, MHIP_EINVAL, "beam_candidates: beam %d", d.beam);
+  CandArgs a;
+  a.logits = d.logits; a.ld = d.ld; a.vocab = d.vocab; a.beam = d.beam; a.cum = d.cum; a.step = d.step;
+  a.max_len = d.max_len; a.min_len = d.min_len; a.pad = d.pad; a.eos = d.eos;
+  a.cand_scores = d.cand_scores; a.cand_tokens = d.cand_tokens; a.cand_beams = d.cand_beams;
+  const int lds = CAND_T * CAND_K * 8;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)beam_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(beam_candidates_kernel, dim3(d.bsz), dim3(CAND_T), lds, ctx->stream, a));
+  CHECK_LAUNCH(ctx, "beam_candidates");
+  return 0;
+}
+
+int mhip_launch_ancestry(mhip_ctx* ctx, const int* anc_old, int* anc_new, const int* parent, int rows, int ld, int step) {
+  const int total = rows * (step + 2);
+  PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(ancestry_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, anc_old, anc_new, parent, rows, ld, step));
+  CHECK_LAUNCH(ctx, "ancestry");
+  return 0;
+}

@@ -1,0 +1,220 @@
+"""TrOCR recognizer on MI355X behind the reference's ``TrOcrProcessor`` surface.
+
+Mirrors ``TrOcrProcessor`` (reference: marie/document/trocr_ocr_processor.py:182-367): ``recognize_from_fragments(images)``
+returns ``[{"confidence": round(exp(score), 4), "id": "img-<k>", "text": TEXT.upper()}]`` in input order.  Fragment
+resize (Pillow bicubic to 384 x 384), the DeiT encoder, the fairseq-style decoder and the beam search run in
+libmarie_hip.so; this file turns token ids into text: fairseq ``Dictionary`` symbols -> GPT-2 byte-level BPE decode
+(marie/models/unilm/trocr/bpe.py:59-67; ``get_text`` :142-180).
+
+The dictionary (``gpt2_with_mask.dict.txt``) and GPT-2's ``encoder.json`` are assets the reference downloads at run time;
+they are not in its tree.  Pass their paths (``dict_path``, ``encoder_json``); without them the processor still runs and
+returns the space-joined token ids as text.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from ._lib import PREC_F16, PREC_F32, Context, MarieHipError, TrocrConfig, check
+from .crnn import pack_fragments
+from .ocr_processor import OcrProcessor
+from .vit import load_tensors
+
+
+def default_config(lib, model: str = "base") -> TrocrConfig:
+    cfg = TrocrConfig()
+    rc = lib.mhip_trocr_default_config(0 if model == "base" else 1, C.byref(cfg))
+    if rc:
+        raise ValueError(f"mhip_trocr_default_config({model}) -> {rc}")
+    return cfg
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
+
+
+class TrocrModel:
+    def __init__(self, ctx: Context, state: Optional[Dict[str, np.ndarray]], config: TrocrConfig, precision: int = PREC_F16):
+        self.ctx, self.lib, self.cfg, self.precision = ctx, ctx.lib, config, int(precision)
+        h = C.c_void_p()
+        check(ctx.h, self.lib.mhip_trocr_create(ctx.h, self.precision, C.byref(config), C.byref(h)), "mhip_trocr_create")
+        self.h = h
+        ctx.adopt(self)
+        self.max_len = self.lib.mhip_trocr_max_len(C.byref(config))
+        if state is not None:
+            load_tensors(ctx, self.lib.mhip_trocr_set_tensor, self.h, state, "mhip_trocr_set_tensor")
+            check(ctx.h, self.lib.mhip_trocr_finalize(self.h), "mhip_trocr_finalize")
+
+    def arenas(self):
+        out = []
+        for which in (0, 1):
+            p, n = C.c_void_p(), C.c_size_t()
+            check(self.ctx.h, self.lib.mhip_trocr_arena(self.h, which, C.byref(p), C.byref(n)), "mhip_trocr_arena")
+            out.append((p.value, n.value))
+        return out
+
+    def alloc_arena(self):
+        check(self.ctx.h, self.lib.mhip_trocr_alloc_arena(self.h), "mhip_trocr_alloc_arena")
+
+    def _outputs(self, n):
+        return (np.empty((n, self.max_len + 1), np.int32), np.empty((n,), np.int32), np.empty((n,), np.float32))
+
+    @staticmethod
+    def _unpack(tokens, lengths, scores):
+        return [(tokens[i, : lengths[i]].copy(), float(scores[i])) for i in range(len(lengths))]
+
+    def generate_host(self, crops_u8: np.ndarray, swap_rb: bool = False, want_taps: bool = False):
+        """crops (n, 384, 384, 3) uint8 -> [(token ids incl. eos, normalised log-prob)] (+ encoder tokens, step-0 logits)."""
+        crops = np.ascontiguousarray(crops_u8, np.uint8)
+        n = crops.shape[0]
+        tokens, lengths, scores = self._outputs(n)
+        enc = np.empty((n, 1 + (self.cfg.img_size // 16) ** 2, self.cfg.enc_dim), np.float32) if want_taps else None
+        lg = np.empty((n, self.cfg.vocab), np.float32) if want_taps else None
+        check(self.ctx.h, self.lib.mhip_trocr_generate_host(self.h, _vp(crops), n, int(swap_rb), _vp(tokens), _vp(lengths),
+                                                            _vp(scores), _vp(enc), _vp(lg)), "mhip_trocr_generate_host")
+        res = self._unpack(tokens, lengths, scores)
+        return (res, enc, lg) if want_taps else res
+
+    def generate_device(self, crops_ptr: int, n: int, swap_rb: bool = False):
+        tokens, lengths, scores = self._outputs(n)
+        check(self.ctx.h, self.lib.mhip_trocr_generate(self.h, C.c_void_p(crops_ptr), n, int(swap_rb), _vp(tokens), _vp(lengths),
+                                                       _vp(scores)), "mhip_trocr_generate")
+        return self._unpack(tokens, lengths, scores)
+
+    def generate_fragments(self, base_ptr: int, descs, n: int, swap_rb: bool = True):
+        tokens, lengths, scores = self._outputs(n)
+        check(self.ctx.h, self.lib.mhip_trocr_generate_fragments(self.h, C.c_void_p(base_ptr), descs, n, int(swap_rb),
+                                                                 _vp(tokens), _vp(lengths), _vp(scores)),
+              "mhip_trocr_generate_fragments")
+        return self._unpack(tokens, lengths, scores)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.mhip_trocr_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------- text side
+def load_fairseq_dictionary(path: str) -> List[str]:
+    """fairseq ``Dictionary.load``: <s>, <pad>, </s>, <unk>, then one ``symbol count`` line each, then ``madeupwordNNNN``
+    fillers up to a multiple of 8."""
+    symbols = ["<s>", "<pad>", "</s>", "<unk>"]
+    with open(path, "r", encoding="utf-8") as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            sym = line.rsplit(" ", 1)[0]
+            if sym.endswith(" #fairseq:overwrite"):
+                sym = sym[: -len(" #fairseq:overwrite")]
+            symbols.append(sym)
+    i = 0
+    while len(symbols) % 8 != 0:
+        symbols.append(f"madeupword{i:04d}")
+        i += 1
+    return symbols
+
+
+def _bytes_to_unicode() -> Dict[int, str]:
+    """GPT-2's reversible byte <-> printable-unicode table."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, [chr(c) for c in cs]))
+
+
+class Gpt2Decoder:
+    """``bpe.decode`` of GPT2BPEEnhancedSpace (INSERT_OR_REPLACE = 0): ids -> byte-level BPE strings -> utf-8, with the
+    ``<s>`` space marker removed."""
+
+    def __init__(self, encoder_json: str):
+        with open(encoder_json, "r", encoding="utf-8") as f:
+            enc = json.load(f)
+        self.decoder = {v: k for k, v in enc.items()}
+        self.byte_decoder = {v: k for k, v in _bytes_to_unicode().items()}
+
+    def decode(self, hypo_str: str) -> str:
+        parts = []
+        for tok in hypo_str.split():
+            parts.append(tok if tok in {"<unk>", "<mask>", "<s>"} else self.decoder[int(tok)])
+        text = "".join(parts)
+        return bytearray([self.byte_decoder[c] for c in text]).decode("utf-8", errors="replace").replace("<s>", "")
+
+
+def hypo_string(tokens: Sequence[int], symbols: Optional[List[str]], eos: int = 2, bos: int = 0, unk: int = 3) -> str:
+    """``Dictionary.string`` as ``utils.post_process_prediction`` calls it: symbols joined by spaces, eos / bos skipped."""
+    out = []
+    for t in tokens:
+        t = int(t)
+        if t == eos or t == bos:
+            continue
+        out.append("<unk>" if t == unk else (symbols[t] if symbols is not None else str(t)))
+    return " ".join(out)
+
+
+class TrOcrProcessor(OcrProcessor):
+    """Drop-in for marie/document/trocr_ocr_processor.py:182."""
+
+    def __init__(self, work_dir: str = "/tmp/icr", model_name_or_path: Optional[str] = None, cuda: bool = True, *,
+                 state: Optional[Dict[str, np.ndarray]] = None, config: Optional[TrocrConfig] = None, model: str = "base",
+                 precision: str = "f16", device_id: int = 0, ctx: Optional[Context] = None, dict_path: Optional[str] = None,
+                 encoder_json: Optional[str] = None, batch_size: int = 256, **kwargs) -> None:
+        super().__init__(work_dir, cuda)
+        if not cuda:
+            raise MarieHipError("TrOcrProcessor here is the MI355X path; cuda=False has no implementation")
+        self.ctx = ctx or Context(device_id)
+        cfg = config or default_config(self.ctx.lib, model)
+        if state is None:
+            if model_name_or_path is None or not os.path.exists(model_name_or_path):
+                raise FileNotFoundError(f"File not found : {model_name_or_path}")
+            import torch
+
+            ck = torch.load(model_name_or_path, map_location="cpu", weights_only=True)
+            sd = ck.get("model", ck)
+            state = {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}
+        self.symbols = load_fairseq_dictionary(dict_path) if dict_path else None
+        if self.symbols is not None and len(self.symbols) != cfg.vocab:
+            raise ValueError(f"dictionary has {len(self.symbols)} symbols, the model expects {cfg.vocab}")
+        self.bpe = Gpt2Decoder(encoder_json) if encoder_json else None
+        prec = {"f16": PREC_F16, "fp16": PREC_F16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
+        self.model = TrocrModel(self.ctx, state, cfg, prec)
+        self.batch_size = int(batch_size)
+
+    def is_available(self) -> bool:
+        return self.model is not None
+
+    def _text(self, tokens) -> str:
+        s = hypo_string(tokens, self.symbols, eos=self.model.cfg.eos)
+        return self.bpe.decode(s) if self.bpe is not None else s
+
+    def recognize_from_fragments(self, src_images, **kwargs) -> List[Dict[str, object]]:
+        import torch
+
+        results: List[Dict[str, object]] = []
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        for start in range(0, len(src_images), self.batch_size):
+            batch = src_images[start:start + self.batch_size]
+            packed, descs = pack_fragments([f if np.ndim(f) == 3 else np.repeat(np.asarray(f)[:, :, None], 3, axis=2) for f in batch])
+            d_in = torch.from_numpy(packed).cuda()
+            hyps = self.model.generate_fragments(d_in.data_ptr(), descs, len(batch), swap_rb=True)   # fragments are BGR
+            for k, (tokens, score) in enumerate(hyps):
+                conf = round(math.exp(score), 6)                 # get_text: round(exp(score), 6), then round(score, 4)
+                text = self._text(tokens)
+                results.append({"confidence": round(conf, 4), "id": f"img-{start + k}", "text": text.upper() if text is not None else ""})
+        return results

@@ -438,3 +438,49 @@ def make_dit_state(seed: int = 0, model: str = "base") -> Dict[str, np.ndarray]:
     st[p + "bbox_pred.weight"] = uni((4, 1024), 2.0 * np.sqrt(3.0 / 1024))
     st[p + "bbox_pred.bias"] = uni((4,), 0.2)
     return st
+
+
+# ------------------------------------------------------------------------------------------------ TrOCR
+def make_trocr_state(seed: int = 0, enc=(768, 12, 12), dec=(1024, 12, 16, 4096), vocab: int = 50265, max_positions: int = 512,
+                     pad: int = 1, img: int = 384, logit_gain: float = 6.0, eos: int = 2, eos_gain: float = 18.0
+                     ) -> Dict[str, np.ndarray]:
+    """Seeded TrOCR weights under fairseq checkpoint key names: ``encoder.deit.*`` (timm VisionTransformer, no qkv bias,
+    final norm) and ``decoder.*`` (TransformerDecoder with RoBERTa arguments: learned positions, layernorm_embedding,
+    post-LN layers, output projection tied to embed_tokens).  ``logit_gain`` spreads the token distribution so beam
+    search has clear winners; ``eos_gain`` adds a constant to the ``</s>`` logit (through the last LayerNorm's bias
+    direction) so hypotheses end at different lengths and crops of one batch finish at different steps."""
+    ed, edepth, eheads = enc
+    D, L, H, F = dec
+    g = img // 16
+    st = {"encoder.deit." + k: v for k, v in
+          make_vit_state(seed, ed, edepth, eheads, pos_hw=(g, g), layer_scale=False, qkv_bias=0, fpn=False, final_norm=True).items()}
+    rng = np.random.Generator(np.random.PCG64(seed + 1299709))
+
+    def uni(shape, bound):
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    st["decoder.embed_tokens.weight"] = uni((vocab, D), logit_gain * np.sqrt(3.0 / D))
+    st["decoder.embed_positions.weight"] = uni((max_positions + pad + 1, D), 0.5)
+    st["decoder.layernorm_embedding.weight"] = rng.uniform(0.7, 1.3, size=(D,)).astype(np.float32)
+    st["decoder.layernorm_embedding.bias"] = uni((D,), 0.1)
+    for l in range(L):
+        p = f"decoder.layers.{l}."
+        for att, kd in (("self_attn", D), ("encoder_attn", ed)):
+            st[p + att + ".q_proj.weight"] = uni((D, D), 2.0 * np.sqrt(3.0 / D))
+            st[p + att + ".k_proj.weight"] = uni((D, kd), 2.0 * np.sqrt(3.0 / kd))
+            st[p + att + ".v_proj.weight"] = uni((D, kd), np.sqrt(3.0 / kd))
+            st[p + att + ".out_proj.weight"] = uni((D, D), np.sqrt(3.0 / D))
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                st[p + att + f".{n}.bias"] = uni((D,), 0.1)
+        st[p + "fc1.weight"] = uni((F, D), np.sqrt(3.0 / D))
+        st[p + "fc1.bias"] = uni((F,), 0.1)
+        st[p + "fc2.weight"] = uni((D, F), np.sqrt(3.0 / F))
+        st[p + "fc2.bias"] = uni((D,), 0.1)
+        for n in ("self_attn_layer_norm", "encoder_attn_layer_norm", "final_layer_norm"):
+            st[p + n + ".weight"] = rng.uniform(0.7, 1.3, size=(D,)).astype(np.float32)
+            st[p + n + ".bias"] = uni((D,), 0.1)
+    if eos_gain:
+        b = uni((D,), 0.6)
+        st[f"decoder.layers.{L - 1}.final_layer_norm.bias"] = b
+        st["decoder.embed_tokens.weight"][eos] += b * np.float32(eos_gain / float((b * b).sum()))
+    return st
