@@ -5,7 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Default workload ``pages`` (BASELINE.json metric: pages/sec on 2550x3300 pages, ~40 lines/page): one *step* = one
+Default workload ``dit_trocr`` = BASELINE configs[2], the configuration the pages/sec metric is quoted on: DiT-base
+Mask R-CNN detector + TrOCR-base recognizer on 2550x3300 pages resident in HBM.  One *step* = ``--pages`` pages per GPU:
+    Pillow-exact bilinear resize to 1035x800 -> DiT-base backbone + FPN + RPN + ROI heads + FastRCNN inference
+    (one detector pass: bbox_refinement=False) -> boxes to the host;
+    40 ground-truth line boxes per page (fixed recognizer work, SURVEY.md section 8d "headline") -> Pillow-exact bicubic to
+    384x384 -> TrOCR-base encoder -> 12-layer decoder, beam 3, ``--decode-len`` + 1 steps (15 + EOS) -> token ids.
+Seeded random weights; with random weights the detector's own boxes are noise, which is why the recognizer consumes the
+generator's line boxes (the detector still runs in full and is timed).
+
+Workload ``craft_crnn`` (BASELINE.json metric: pages/sec on 2550x3300 pages, ~40 lines/page): one *step* = one
 pass of detect -> crop -> recognize over a batch of ``--pages`` synthetic 2550x3300x3 uint8 pages per GPU that are
 already resident in HBM:
     CRAFT detector (cv2-exact resize to the 1970x2550 canvas, normalise, VGG16-BN + U-net, score maps) ->
@@ -112,14 +121,191 @@ def cpu_baseline_pages(craft_state, crnn_state, charset, img_w, n_lines):
                       f"({len(rects)} boxes; torch CPU forward + the reference's per-component numpy loop), "
                       f"{n_lines} line crops + recognizer {t2 - t1:.2f} s"}
 
+def cpu_baseline_dit_trocr(dit_state, trocr_state, trocr_dims, decode_len, n_lines):
+    """The CPU oracle pipeline on a bounded sample (rank 0, N=1 only): one full 2550x3300 page through the DiT-base
+    detector (one pass) and 3 line crops through TrOCR-base, beam 3; the recognizer time is scaled to n_lines crops."""
+    import torch
+
+    from marie_icr_amd.weights import make_page_bgr, page_line_boxes
+    from oracle.dit_torch import TorchDitOracle
+    from oracle.trocr_torch import TorchTrocrOracle, preprocess_fragments
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    page = make_page_bgr(999, PAGE_H, PAGE_W, n_lines=n_lines)
+    lines = page_line_boxes(PAGE_H, PAGE_W, n_lines)
+    det = TorchDitOracle(dit_state)
+    t0 = time.perf_counter()
+    boxes, _ = det.detect(page)
+    t1 = time.perf_counter()
+    enc, dec, vocab = trocr_dims
+    rec = TorchTrocrOracle(trocr_state, enc[2], dec[2], beam=3, max_len_b=decode_len)
+    k = 3
+    frags = [page[y:y + h + 1, x:x + w + 1] for x, y, w, h in lines[:k].tolist()]
+    t2 = time.perf_counter()
+    rec.generate(preprocess_fragments(frags))
+    t3 = time.perf_counter()
+    per_page = (t1 - t0) + (t3 - t2) / k * n_lines
+    return {"value": 1.0 / per_page, "unit": "pages/s", "cores": cores, "kind": "port",
+            "sample": f"1 of the same seeded {PAGE_W}x{PAGE_H} pages through the detector oracle ({t1 - t0:.1f} s, "
+                      f"{len(boxes)} boxes, torch CPU fp32) + {k} of its {n_lines} line crops through the TrOCR oracle "
+                      f"({(t3 - t2) / k:.2f} s/crop, beam 3, {decode_len}+1 steps), recognizer time scaled to {n_lines} crops"}
+
+
+def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
+    """BASELINE configs[2]: DiT-base detector + TrOCR-base recognizer, full pages, one GPU per rank."""
+    import ctypes as C
+    import threading
+
+    from marie_icr_amd._lib import Context, CropDesc
+    from marie_icr_amd.dist import broadcast_arenas
+    from marie_icr_amd.dit import DitModel
+    from marie_icr_amd.trocr import TrocrModel, default_config as trocr_config
+    from marie_icr_amd.weights import make_dit_state, make_page_bgr, make_trocr_state, page_line_boxes
+
+    P, DB = args.pages, max(1, min(args.det_batch, args.pages))
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    ctxs = [Context(local_rank), Context(local_rank)]
+    for c, s_ in zip(ctxs, streams):
+        c.set_stream(s_.cuda_stream)
+    tcfg = trocr_config(ctxs[1].lib, "base")
+    tcfg.max_len_b = args.decode_len
+    dims = ((tcfg.enc_dim, tcfg.enc_depth, tcfg.enc_heads), (tcfg.dec_dim, tcfg.dec_layers, tcfg.dec_heads, tcfg.dec_ffn),
+            tcfg.vocab)
+    dit_state = make_dit_state(0, args.model) if rank == 0 else None
+    trocr_state = make_trocr_state(0, dims[0], dims[1], dims[2], tcfg.max_positions) if rank == 0 else None
+    det = DitModel(ctxs[0], dit_state, model=args.model, precision=prec)
+    rec = TrocrModel(ctxs[1], trocr_state, tcfg, prec)
+    if world > 1:      # rank 0 packed the weights; everyone else receives the packed arenas over RCCL / xGMI
+        for m, c, s_ in ((det, ctxs[0], streams[0]), (rec, ctxs[1], streams[1])):
+            if rank != 0:
+                m.alloc_arena()
+            with torch.cuda.stream(s_):
+                broadcast_arenas(m, c, dist, src=0)
+    host_pages = np.stack([make_page_bgr(1000 + rank * 97 + i, PAGE_H, PAGE_W, n_lines=LINES_PER_PAGE) for i in range(min(P, 4))])
+    pages = torch.from_numpy(host_pages[np.arange(P) % len(host_pages)]).cuda()     # [P][H][W][3] in HBM
+    page_bytes = PAGE_H * PAGE_W * 3
+    gt = page_line_boxes(PAGE_H, PAGE_W, LINES_PER_PAGE)
+    n_crops = P * LINES_PER_PAGE
+    descs = (CropDesc * n_crops)()
+    i = 0
+    for pi in range(P):
+        for x, y, w, h in gt.tolist():
+            descs[i] = CropDesc(pi * page_bytes + (y * PAGE_W + x) * 3, h + 1, w + 1, PAGE_W * 3, 3)
+            i += 1
+    stats = {"boxes": 0}
+    last = [None]
+
+    def detect_all():
+        nb = 0
+        for s0 in range(0, P, DB):
+            ptrs = [pages.data_ptr() + pi * page_bytes for pi in range(s0, min(P, s0 + DB))]
+            for boxes, _scores in det.detect_device(ptrs, PAGE_H, PAGE_W):
+                nb += len(boxes)
+        stats["boxes"] += nb
+
+    def recognize_all():
+        last[0] = rec.generate_fragments(pages.data_ptr(), descs, n_crops, swap_rb=True)
+
+    def run(k):
+        # the detector and the recognizer of a step work on the same pages but do not depend on each other here (the
+        # recognizer consumes ground-truth boxes), so they run as two host threads on two streams
+        def loop(fn):
+            for _ in range(k):
+                fn()
+        ths = [threading.Thread(target=loop, args=(f,)) for f in (detect_all, recognize_all)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(max(1, args.warmup))
+    fence()
+    stats["boxes"] = 0
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    boxes_pp = stats["boxes"] / (args.steps * P)
+
+    prof = None
+    if not args.no_kernel_timing:      # one more step, the two halves one after the other, HIP events per kernel
+        for c in ctxs:
+            c.profile_reset()
+            c.profile_enable(True)
+        detect_all()
+        torch.cuda.synchronize()
+        recognize_all()
+        fence()
+        prof = {}
+        for c in ctxs:
+            for name, v in c.profile_read().items():
+                acc = prof.setdefault(name, {"total_ms": 0.0, "launches": 0, "flops": 0.0})
+                for kk in acc:
+                    acc[kk] += v[kk]
+            c.profile_enable(False)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return
+    rate = world * P * args.steps / dt
+    nh, nw, H32, W32 = det.resized_shape(PAGE_H, PAGE_W)
+    out = {
+        "metric": "pages/sec (2550x3300, ~40 lines/page)", "value": rate, "unit": "pages/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[2]: full detect->crop->recognize, {P} synthetic {PAGE_W}x{PAGE_H}x3 u8 pages per "
+                        f"GPU per step resident in HBM; DiT-{args.model} Mask R-CNN detector (resize to {nh}x{nw}, 1 pass, "
+                        f"{args.det_batch} pages per forward) + TrOCR-base recognizer on the generator's {LINES_PER_PAGE} "
+                        f"ground-truth line boxes per page (fixed work), beam 3, {args.decode_len}+1 decoder steps; seeded "
+                        f"random weights",
+            "pages_per_gpu_per_step": P, "crops_per_page": LINES_PER_PAGE, "detector_boxes_per_page": boxes_pp,
+            "parallelism": f"dp{world} (independent pages); detector and recognizer on two streams per GPU",
+        },
+    }
+    if prof is not None:
+        k = prof["conv_igemm"]
+        ach = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
+        peak = PEAK_MFMA_TFLOPS_F16 if args.precision == "f16" else PEAK_MFMA_TFLOPS_F32
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "conv_igemm", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": None, "launches_per_step": k["launches"], "avg_launch_ms": k["total_ms"] / max(k["launches"], 1),
+            "algorithmic_gflop_per_step": k["flops"] / 1e9,
+            "measured": "HIP events on the launch streams, detector then recognizer alone, same step right after the "
+                        "timed region; FLOPs = 2*MAC of every launch (mhip_profile_flops)",
+        }
+        a = prof["attn_flash"]
+        out["roofline_attention"] = {"kernel": "attn_flash", "bound": "mfma",
+                                     "achieved": a["flops"] / (a["total_ms"] * 1e-3) / 1e12 if a["total_ms"] > 0 else 0.0,
+                                     "peak": peak, "unit": "TFLOP/s", "algorithmic_gflop_per_step": a["flops"] / 1e9}
+        out["kernels_ms_per_step"] = {n: v["total_ms"] for n, v in prof.items() if v["launches"]}
+        out["kernel_ms_over_wall_ms"] = sum(out["kernels_ms_per_step"].values()) / (1e3 * dt / args.steps)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_dit_trocr(dit_state, trocr_state, dims, args.decode_len, LINES_PER_PAGE)
+    out["sample_output"] = [[int(t) for t in last[0][0][0]], last[0][0][1]] if last[0] else None
+    print(json.dumps(out), flush=True)
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["pages", "crnn"], default="pages")
-    ap.add_argument("--pages", type=int, default=12, help="pages per GPU per step (workload pages)")
+    ap.add_argument("--workload", choices=["dit_trocr", "craft_crnn", "pages", "crnn"], default="dit_trocr")
+    ap.add_argument("--pages", type=int, default=0, help="pages per GPU per step (default: 16 dit_trocr, 12 craft_crnn)")
+    ap.add_argument("--det-batch", type=int, default=8, help="pages per detector forward (dit_trocr)")
+    ap.add_argument("--decode-len", type=int, default=15, help="generated tokens before the forced EOS (dit_trocr)")
+    ap.add_argument("--model", choices=["base", "large"], default="base", help="DiT detector size (dit_trocr)")
     ap.add_argument("--crops", choices=["lines", "detector"], default="lines")
     ap.add_argument("--inflight", type=int, default=6,
                     help="page pipelines per GPU (one context + stream + host thread each): the host-side box "
@@ -130,6 +316,10 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "pages":
+        args.workload = "craft_crnn"
+    if args.pages <= 0:
+        args.pages = 16 if args.workload == "dit_trocr" else 12
 
     import torch
 
@@ -157,7 +347,13 @@ def main():
                                        make_page_bgr, page_line_boxes)
 
     prec = PREC_F16 if args.precision == "f16" else PREC_F32
-    n_pipe = max(1, args.inflight) if args.workload == "pages" else 1
+    if args.workload == "dit_trocr":
+        run_dit_trocr(args, torch, dist, rank, local_rank, world, prec)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    n_pipe = max(1, args.inflight) if args.workload == "craft_crnn" else 1
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_pipe - 1)]
     ctxs = [Context(local_rank) for _ in range(n_pipe)]
     for c, s_ in zip(ctxs, streams):
@@ -166,7 +362,7 @@ def main():
 
     # ---- weights: rank 0 packs, everyone else receives the packed arenas over RCCL ----------
     crnn_state = make_crnn_state(0)
-    craft_state = make_craft_bench_state() if args.workload == "pages" else None
+    craft_state = make_craft_bench_state() if args.workload == "craft_crnn" else None
 
     def load(cls, c, state, **kw):
         if world > 1:
@@ -179,7 +375,7 @@ def main():
         return cls(c, state, precision=prec, **kw)
 
     recs = [load(CrnnModel, c, crnn_state, num_class=95) for c in ctxs]
-    dets = [load(CraftModel, c, craft_state) for c in ctxs] if args.workload == "pages" else []
+    dets = [load(CraftModel, c, craft_state) for c in ctxs] if args.workload == "craft_crnn" else []
     rec = recs[0]
     det = dets[0] if dets else None
 
@@ -293,10 +489,10 @@ def main():
     prof = None
     prof_steps = 0
     if not args.no_kernel_timing:
-        prof_steps = 1 if args.workload == "pages" else min(args.steps, 5)
+        prof_steps = 1 if args.workload == "craft_crnn" else min(args.steps, 5)
         ctx.profile_reset()
         ctx.profile_enable(True)
-        if args.workload == "pages":
+        if args.workload == "craft_crnn":
             worker_all = n_pipe
             n_pipe_saved = n_pipe
             # pipeline 0 processes every page of the step alone
@@ -331,7 +527,7 @@ def main():
 
     if rank == 0:
         rate = world * units_per_step * args.steps / dt
-        if args.workload == "pages":
+        if args.workload == "craft_crnn":
             P = args.pages
             crops_pp = stats["crops"] / (args.steps * P)
             out = {
@@ -346,8 +542,7 @@ def main():
                     "pages_per_gpu_per_step": P, "crops_per_page": crops_pp,
                     "detector_boxes_per_page": stats["boxes"] / (args.steps * P),
                     "parallelism": f"dp{world} (independent pages), {n_pipe} page pipelines in flight per GPU",
-                    "not_in_this_number": "DiT Mask R-CNN detector and TrOCR recognizer (BASELINE configs[2..4]) "
-                                          "are not built yet",
+                    "note": "secondary workload; the default (dit_trocr) is BASELINE configs[2]",
                 },
             }
             flops_step = P * det.kernel_flops(PAGE_H, PAGE_W)["conv_igemm"] + \
@@ -379,14 +574,14 @@ def main():
                 "frac": achieved / peak, "traffic": None,
                 "launches_per_step": k["launches"] / prof_steps,
                 "measured": "HIP events on the launch stream, one page pipeline alone, same step right after the "
-                            "timed region" if args.workload == "pages" else "HIP events on the launch stream",
+                            "timed region" if args.workload == "craft_crnn" else "HIP events on the launch stream",
                 "avg_launch_ms": k["total_ms"] / max(k["launches"], 1),
                 "algorithmic_gflop_per_step": flops_step / 1e9,
             }
             out["kernels_ms_per_step"] = {name: v["total_ms"] / prof_steps for name, v in prof.items() if v["launches"]}
             out["kernel_ms_over_wall_ms"] = sum(out["kernels_ms_per_step"].values()) / (1e3 * dt / args.steps)
         if world == 1 and not args.no_cpu_baseline:
-            if args.workload == "pages":
+            if args.workload == "craft_crnn":
                 out["cpu_baseline"] = cpu_baseline_pages(craft_state, crnn_state, CRNN_CHARSET, w, LINES_PER_PAGE)
             else:
                 out["cpu_baseline"] = cpu_baseline_crnn(crnn_state, CRNN_CHARSET, w)

@@ -70,6 +70,17 @@ struct Cfg {
   static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 };
 
+// erf GELU (torch.nn.functional.gelu / nn.GELU()).  erf by Abramowitz & Stegun 7.1.26 — |error| <= 1.5e-7 absolute, i.e.
+// about one fp32 ulp of (1 + erf) — branch-free: one v_rcp, one v_exp and five FMAs instead of ocml erff's two-branch
+// polynomial (the fc1 GEMM applies this to 3072 columns of every token).
+__device__ __forceinline__ float gelu_erf(float t) {
+  const float x = t * 0.70710678118654752f, ax = fabsf(x);
+  const float u = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * u - 1.453152027f) * u + 1.421413741f) * u - 0.284496736f) * u + 0.254829592f) * u;
+  const float e = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  return 0.5f * t * (1.f + copysignf(e, x));
+}
+
 template <int POOL>
 __device__ __forceinline__ void decode_row(const IgemmArgs& p, int m, int& b, int& y, int& x) {
   if (POOL == POOL_NONE) {
@@ -206,8 +217,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 
   // ---- main loop: NSTAGE-slot ring, GL LDS-DMA instructions per wave per (half-)slice -------
   constexpr int D = C::NSTAGE - 1;  // (half-)slices in flight ahead of the one being computed
+#ifdef IGEMM_DBG_NO_LOOP
+  const int nsteps = 0;
+#else
   const int nsteps = C::KSPLIT ? 2 * p.nslices : p.nslices;
-  stage(0, 0);
+#endif
+  if (nsteps > 0) stage(0, 0);
   if (D > 1 && nsteps > 1) stage(1, 1);
   if (D > 2 && nsteps > 2) stage(2, 2);
   int slot = 0, fill = D % C::NSTAGE;
@@ -249,16 +264,34 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     fill = (fill == C::NSTAGE - 1) ? 0 : fill + 1;
   }
 
-  // ---- epilogue: scale/bias, ReLU, in-register max-pool -> LDS -> coalesced NHWC stores ----
-  // done in passes of 128 output columns so the staging tile fits next to nothing else in LDS
+#ifdef IGEMM_DBG_NO_EPI
+  if (acc[0][0][0] == 123.456f) *(float*)p.out = acc[1][1][1];
+  return;
+#endif
+  // ---- epilogue: scale/bias, activation, in-register max-pool -> LDS (fp32) -> coalesced NHWC stores ----
+  // Staging is ALWAYS fp32: one ds_write_b32 per value, every lane its own bank.  (Staging f16 put two lanes into each
+  // dword; those sub-dword writes cost ~56 cycles per wave-instruction and made the epilogue 30 us per tile — more than
+  // the whole K = 768 main loop.  profiles/r01/i_epilogue.txt.)  Done in passes of 128 output columns.
   constexpr int PF = (POOL == POOL_2x2) ? 4 : (POOL == POOL_2x1) ? 2 : 1;
   constexpr int RQ = BM / PF;  // output rows of this tile
   const int Mq = p.M / PF;
   const int q0 = m0 / PF;
   const int oe = p.out_f32 ? 4 : (int)sizeof(T);
   constexpr int EPW = C::EPW;
-  const int pitch = EPW * oe + 16;
+  constexpr int SP = EPW * 4 + 16;     // staged row pitch in bytes
   const size_t grow = (size_t)(p.ldc ? p.ldc : p.N) * oe;  // global bytes per output pixel
+  // ReLU without a residual is applied here (branch-free); with a residual it follows the add, and GELU is applied in
+  // the copy-out loop — a ROLLED loop, so erff is inlined 8 times, not once per accumulator register (128 copies of it
+  // made this kernel 160 KB of code and the epilogue instruction-fetch bound).
+  const float lo = (p.relu == ACT_RELU && !p.res) ? 0.f : -INFINITY;
+  const bool gelu = p.relu == ACT_GELU;
+  float sc4[4], bi4[4];                // this lane's 4 output columns (its wave takes part in exactly one pass)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + (wc >> 1) * EPW + (wc & 1) * 64 + j * 16 + frow;
+    sc4[j] = (p.scale && n < p.N) ? p.scale[n] : 1.f;
+    bi4[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+  }
 #pragma unroll
   for (int pass = 0; pass < C::BN / EPW; ++pass) {
     __syncthreads();  // ring (or previous pass) fully consumed
@@ -266,66 +299,65 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int lc = (wc & 1) * 64 + j * 16 + frow;
-        const int n = n0 + pass * EPW + lc;
-        const float sc = (p.scale && n < p.N) ? p.scale[n] : 1.f;
-        const float bi = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        const float sc = sc4[j], bi = bi4[j];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float t = acc[i][j][r] * sc + bi;
-            if (p.relu == ACT_GELU) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));   // exact (erf) GELU
-            else if (p.relu == ACT_RELU && !p.res) t = fmaxf(t, 0.f);   // with a residual the ReLU follows the add
-            v[r] = t;
-          }
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[i][j][r] * sc + bi, lo);
           const int lr4 = wr * (MT * 16) + i * 16 + fg * 4;  // first of this lane's 4 consecutive tile rows
           if (POOL == POOL_2x2) {
-            float o = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            if (p.out_f32) lds_put<float>(smem, pitch, lr4 >> 2, lc, o);
-            else lds_put<T>(smem, pitch, lr4 >> 2, lc, o);
+            lds_put<float>(smem, SP, lr4 >> 2, lc, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
           } else if (POOL == POOL_2x1) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              float o = fmaxf(v[2 * h], v[2 * h + 1]);
-              if (p.out_f32) lds_put<float>(smem, pitch, (lr4 >> 1) + h, lc, o);
-              else lds_put<T>(smem, pitch, (lr4 >> 1) + h, lc, o);
-            }
+            for (int h = 0; h < 2; ++h) lds_put<float>(smem, SP, (lr4 >> 1) + h, lc, fmaxf(v[2 * h], v[2 * h + 1]));
           } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (p.out_f32) lds_put<float>(smem, pitch, lr4 + r, lc, v[r]);
-              else lds_put<T>(smem, pitch, lr4 + r, lc, v[r]);
-            }
+            for (int r = 0; r < 4; ++r) lds_put<float>(smem, SP, lr4 + r, lc, v[r]);
           }
         }
       }
     }
     __syncthreads();
     const int nbase = n0 + pass * EPW;
-    if ((grow & 15) == 0) {
-      const int cpr = EPW * oe / 16;       // 16-B chunks per staged row
-      const int epc = 16 / oe;             // elements per chunk
+    if ((grow & 15) == 0 && oe == 4) {          // fp32 out: 4 columns per thread
+      constexpr int cpr = EPW / 4;
       for (int c = tid; c < RQ * cpr; c += NTHREADS) {
         const int row = c / cpr, ch = c - row * cpr;
-        const int q = q0 + row, n = nbase + ch * epc;
+        const int q = q0 + row, n = nbase + ch * 4;
         if (q < Mq && n < p.N) {
-          uint4v val = *(const uint4v*)(smem + row * pitch + ch * 16);
+          float4v a = *(const float4v*)(smem + row * SP + ch * 16);
+          if (gelu)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = gelu_erf(a[k]);
           if (p.res) {   // out = act(conv + residual): residual read with the same 16-byte coalescing as the store
-            uint4v rv = *(const uint4v*)(p.res + (size_t)q * grow + (size_t)n * oe);
-            if (oe == 4) {
-              float4v a = *(float4v*)&val, r4 = *(float4v*)&rv;
+            const float4v r4 = *(const float4v*)(p.res + (size_t)q * grow + (size_t)n * 4);
 #pragma unroll
-              for (int k = 0; k < 4; ++k) { float t = a[k] + r4[k]; a[k] = p.relu == ACT_RELU ? fmaxf(t, 0.f) : t; }
-              val = *(uint4v*)&a;
-            } else {
-              half8 a = *(half8*)&val, r8 = *(half8*)&rv;
-#pragma unroll
-              for (int k = 0; k < 8; ++k) { float t = (float)a[k] + (float)r8[k]; a[k] = (_Float16)(p.relu == ACT_RELU ? fmaxf(t, 0.f) : t); }
-              val = *(uint4v*)&a;
-            }
+            for (int k = 0; k < 4; ++k) { const float t = a[k] + r4[k]; a[k] = p.relu == ACT_RELU ? fmaxf(t, 0.f) : t; }
           }
-          *(uint4v*)(p.out + (size_t)q * grow + (size_t)n * oe) = val;
+          *(float4v*)(p.out + (size_t)q * grow + (size_t)n * 4) = a;
+        }
+      }
+    } else if ((grow & 15) == 0) {               // f16 out: 8 columns per thread, one 16-byte store
+      constexpr int cpr = EPW / 8;
+      for (int c = tid; c < RQ * cpr; c += NTHREADS) {
+        const int row = c / cpr, ch = c - row * cpr;
+        const int q = q0 + row, n = nbase + ch * 8;
+        if (q < Mq && n < p.N) {
+          const float4v a0 = *(const float4v*)(smem + row * SP + ch * 32), a1 = *(const float4v*)(smem + row * SP + ch * 32 + 16);
+          float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          if (gelu)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = gelu_erf(f[k]);
+          if (p.res) {
+            const half8 r8 = *(const half8*)(p.res + (size_t)q * grow + (size_t)n * 2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float t = f[k] + (float)r8[k]; f[k] = p.relu == ACT_RELU ? fmaxf(t, 0.f) : t; }
+          }
+          half8 o;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = (_Float16)f[k];
+          *(half8*)(p.out + (size_t)q * grow + (size_t)n * 2) = o;
         }
       }
     } else {  // ragged N (e.g. the 95-class prediction layer): element-wise
@@ -333,8 +365,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
         const int row = e / EPW, col = e - row * EPW;
         const int q = q0 + row, n = nbase + col;
         if (q < Mq && n < p.N) {
-          if (oe == 4) *(float*)(p.out + (size_t)q * grow + (size_t)n * 4) = *(const float*)(smem + row * pitch + col * 4);
-          else *(T*)(p.out + (size_t)q * grow + (size_t)n * sizeof(T)) = *(const T*)(smem + row * pitch + col * (int)sizeof(T));
+          float v = *(const float*)(smem + row * SP + col * 4);
+          if (gelu) v = gelu_erf(v);
+          if (oe == 4) *(float*)(p.out + (size_t)q * grow + (size_t)n * 4) = v;
+          else *(T*)(p.out + (size_t)q * grow + (size_t)n * sizeof(T)) = (T)v;
         }
       }
     }

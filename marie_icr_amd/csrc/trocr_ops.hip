@@ -108,71 +108,93 @@ struct DecAttnArgs {
   int n_keys, nq;
 };
 
-constexpr int DA_MAXK = 640, DA_MAXQ = 4;
+constexpr int DA_MAXK = 640, DA_MAXQ = 4, DA_WAVES = 4;
 
+// One WAVE per (group, head): a 16-byte chunk of a key row per lane, so a wave-instruction reads whole 128-byte (f16) /
+// 256-byte (fp32) head rows of 8 / 4 consecutive keys — every K and V byte is fetched once, fully coalesced.
 template <typename T>
-__global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
-  __shared__ float sq[DA_MAXQ][64];
-  __shared__ float sp[DA_MAXQ][DA_MAXK];
-  __shared__ float red[DA_MAXQ][4][64];
-  __shared__ float smax[DA_MAXQ], ssum[DA_MAXQ];
-  const int h = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x;
+__global__ __launch_bounds__(64 * DA_WAVES) void decode_attn_kernel(DecAttnArgs p, int heads, int tasks) {
+  constexpr int EPC = 16 / (int)sizeof(T);        // elements per chunk: 8 / 4
+  constexpr int CPR = 64 / EPC;                   // chunks per head row: 8 / 16
+  constexpr int KPI = 64 / CPR;                   // keys per wave-instruction: 8 / 4
+  __shared__ float sp[DA_WAVES][DA_MAXQ][DA_MAXK];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int task = blockIdx.x * DA_WAVES + wave;
+  const bool live = task < tasks;
+  const int h = live ? task % heads : 0, grp = live ? task / heads : 0;
   const int row0 = grp * p.nq;
-  for (int e = tid; e < p.nq * 64; e += 256) sq[e >> 6][e & 63] = (float)((const T*)p.q)[(size_t)(row0 + (e >> 6)) * p.ldq + h * 64 + (e & 63)];
-  __syncthreads();
+  const int c = lane % CPR, ks = lane / CPR;
   auto key_row = [&](int s) -> size_t {
     return p.anc ? ((size_t)s * p.slots + p.anc[(size_t)row0 * p.anc_ld + s]) : ((size_t)grp * p.kv_rows + s);
   };
-  // scores
-  for (int s = tid; s < p.n_keys; s += 256) {
-    const T* kr = (const T*)p.k + key_row(s) * p.ldk + h * 64;
-    float acc[DA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
-    for (int d = 0; d < 64; d += 8) {
-      float kv[8];
+  float q[DA_MAXQ][EPC];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) kv[j] = (float)kr[d + j];
+  for (int qi = 0; qi < DA_MAXQ; ++qi)
 #pragma unroll
-      for (int qi = 0; qi < DA_MAXQ; ++qi)
-        if (qi < p.nq)
+    for (int j = 0; j < EPC; ++j)
+      q[qi][j] = (live && qi < p.nq) ? (float)((const T*)p.q)[(size_t)(row0 + qi) * p.ldq + h * 64 + c * EPC + j] : 0.f;
+  // scores: lanes of one key (CPR of them) each hold a partial dot product
+  if (live)
+    for (int s = ks; s < p.n_keys; s += KPI) {
+      const T* kr = (const T*)p.k + key_row(s) * p.ldk + h * 64 + c * EPC;
+      T kv[EPC];
+      *(uint4*)kv = *(const uint4*)kr;
+      float part[DA_MAXQ];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[qi] += sq[qi][d + j] * kv[j];
+      for (int qi = 0; qi < DA_MAXQ; ++qi) {
+        part[qi] = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) part[qi] += q[qi][j] * (float)kv[j];
+#pragma unroll
+        for (int o = 1; o < CPR; o <<= 1) part[qi] += __shfl_xor(part[qi], o);
+      }
+      if (c == 0)
+        for (int qi = 0; qi < p.nq; ++qi) sp[wave][qi][s] = part[qi];
     }
-    for (int qi = 0; qi < p.nq; ++qi) sp[qi][s] = acc[qi];
-  }
   __syncthreads();
-  // softmax per query: wave qi handles query qi
-  {
-    const int qi = tid >> 6, lane = tid & 63;
-    if (qi < p.nq) {
+  float inv[DA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
+  if (live)
+    for (int qi = 0; qi < p.nq; ++qi) {
       float m = -INFINITY;
-      for (int s = lane; s < p.n_keys; s += 64) m = fmaxf(m, sp[qi][s]);
+      for (int s = lane; s < p.n_keys; s += 64) m = fmaxf(m, sp[wave][qi][s]);
 #pragma unroll
       for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
       float sum = 0.f;
-      for (int s = lane; s < p.n_keys; s += 64) { const float e = expf(sp[qi][s] - m); sp[qi][s] = e; sum += e; }
-      sum = wave_sum(sum);
-      if (lane == 0) { smax[qi] = m; ssum[qi] = sum; }
+      for (int s = lane; s < p.n_keys; s += 64) { const float e = expf(sp[wave][qi][s] - m); sp[wave][qi][s] = e; sum += e; }
+      inv[qi] = 1.f / wave_sum(sum);
     }
-  }
   __syncthreads();
-  // weighted values: thread (d = tid & 63, part = tid >> 6) sums keys = part mod 4
-  {
-    const int d = tid & 63, part = tid >> 6;
-    float acc[DA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = part; s < p.n_keys; s += 4) {
-      const float vv = (float)((const T*)p.v)[key_row(s) * p.ldk + h * 64 + d];
+  if (!live) return;
+  // weighted values: lane (c, ks) accumulates its chunk of d over keys ks, ks + KPI, ...
+  float acc[DA_MAXQ][EPC];
 #pragma unroll
-      for (int qi = 0; qi < DA_MAXQ; ++qi)
-        if (qi < p.nq) acc[qi] += sp[qi][s] * vv;
+  for (int qi = 0; qi < DA_MAXQ; ++qi)
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) acc[qi][j] = 0.f;
+  for (int s = ks; s < p.n_keys; s += KPI) {
+    const T* vr = (const T*)p.v + key_row(s) * p.ldk + h * 64 + c * EPC;
+    T vv[EPC];
+    *(uint4*)vv = *(const uint4*)vr;
+#pragma unroll
+    for (int qi = 0; qi < DA_MAXQ; ++qi) {
+      const float w = qi < p.nq ? sp[wave][qi][s] : 0.f;
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) acc[qi][j] += w * (float)vv[j];
     }
-    for (int qi = 0; qi < p.nq; ++qi) red[qi][part][d] = acc[qi];
   }
-  __syncthreads();
-  for (int e = tid; e < p.nq * 64; e += 256) {
-    const int qi = e >> 6, d = e & 63;
-    const float o = (red[qi][0][d] + red[qi][1][d]) + (red[qi][2][d] + red[qi][3][d]);
-    ((T*)p.out)[(size_t)(row0 + qi) * p.ldo + h * 64 + d] = (T)(o / ssum[qi]);
-  }
+#pragma unroll
+  for (int qi = 0; qi < DA_MAXQ; ++qi)
+#pragma unroll
+    for (int j = 0; j < EPC; ++j)
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) acc[qi][j] += __shfl_xor(acc[qi][j], o);
+  if (ks == 0)
+    for (int qi = 0; qi < p.nq; ++qi) {
+      T o[EPC];
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) o[j] = (T)(acc[qi][j] * inv[qi]);
+      *(uint4*)((T*)p.out + (size_t)(row0 + qi) * p.ldo + h * 64 + c * EPC) = *(uint4*)o;
+    }
 }
 
 // ---- beam candidates ---------------------------------------------------------------------------------------------------
@@ -318,9 +340,10 @@ int mhip_launch_decode_attention(mhip_ctx* ctx, int precision, const DecAttnDesc
   DecAttnArgs a;
   a.q = d.q; a.k = d.k; a.v = d.v; a.out = d.out; a.anc = d.anc; a.anc_ld = d.anc_ld; a.slots = d.slots;
   a.kv_rows = d.kv_rows; a.ldq = d.ldq; a.ldk = d.ldk; a.ldo = d.ldo; a.n_keys = d.n_keys; a.nq = d.nq;
-  dim3 grid(d.heads, d.groups), block(256);
-  if (precision == MHIP_PREC_F16) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(decode_attn_kernel<_Float16>, grid, block, 0, ctx->stream, a));
-  else PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(decode_attn_kernel<float>, grid, block, 0, ctx->stream, a));
+  const int tasks = d.heads * d.groups;
+  dim3 grid((tasks + DA_WAVES - 1) / DA_WAVES), block(64 * DA_WAVES);
+  if (precision == MHIP_PREC_F16) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(decode_attn_kernel<_Float16>, grid, block, 0, ctx->stream, a, d.heads, tasks));
+  else PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(decode_attn_kernel<float>, grid, block, 0, ctx->stream, a, d.heads, tasks));
   CHECK_LAUNCH(ctx, "decode_attention");
   return 0;
 }

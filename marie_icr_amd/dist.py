@@ -51,3 +51,20 @@ def broadcast_arena(model, ctx, dist, src: int = 0) -> None:
         ctx.memcpy_dev(ptr, buf.data_ptr(), nbytes)
     ctx.synchronize()
     torch.cuda.synchronize()
+
+
+def broadcast_arenas(model, ctx, dist, src: int = 0) -> None:
+    """Same as :func:`broadcast_arena` for models that keep several arenas (``model.arenas()`` -> [(ptr, bytes), ...]:
+    the DiT detector and TrOCR keep the ViT encoder and the heads / decoder apart)."""
+    import torch
+
+    for ptr, nbytes in model.arenas():
+        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        if dist.get_rank() == src:
+            ctx.memcpy_dev(buf.data_ptr(), ptr, nbytes)
+            ctx.synchronize()
+        dist.broadcast(buf, src=src)
+        if dist.get_rank() != src:
+            ctx.memcpy_dev(ptr, buf.data_ptr(), nbytes)
+        ctx.synchronize()
+    torch.cuda.synchronize()

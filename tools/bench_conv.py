@@ -23,6 +23,19 @@ SETS = {
         ("xproj1 512->2048 f32", (64512, 1, 1, 512, 1, 0, 2048, 0, 0, 1)),
         ("lin 512->256", (64512, 1, 1, 512, 1, 0, 256, 0, 0, 0)),
     ],
+    "vit": [  # ViT encoder GEMMs: 640 TrOCR crops x 640 rows, and 8 DiT pages x 3328 rows
+        ("trocr qk 768->1536", (640, 1, 640, 768, 1, 0, 1536, 0, 0, 0)),
+        ("trocr proj 768->768 f32", (640, 1, 640, 768, 1, 0, 768, 0, 0, 1)),
+        ("trocr fc1 768->3072 gelu", (640, 1, 640, 768, 1, 0, 3072, 0, 2, 0)),
+        ("trocr fc2 3072->768 f32", (640, 1, 640, 3072, 1, 0, 768, 0, 0, 1)),
+        ("dit qk 768->1536", (8, 1, 3328, 768, 1, 0, 1536, 0, 0, 0)),
+        ("dit fc1 768->3072 gelu", (8, 1, 3328, 768, 1, 0, 3072, 0, 2, 0)),
+        ("dit fc2 3072->768 f32", (8, 1, 3328, 3072, 1, 0, 768, 0, 0, 1)),
+        ("dec fc1 1024->4096 M=1920", (1, 1, 1920, 1024, 1, 0, 4096, 0, 2, 0)),
+        ("dec out 1024->50265 M=1920 f32", (1, 1, 1920, 1024, 1, 0, 50265, 0, 0, 1)),
+    ],
+    "ksweep": [("K=%d N=1536" % k, (640, 1, 640, k, 1, 0, 1536, 0, 0, 0)) for k in (64, 128, 256, 512, 768, 1536, 3072)] +
+              [("K=768 N=%d" % n, (640, 1, 640, 768, 1, 0, n, 0, 0, 0)) for n in (128, 256, 512, 3072)],
     "craft": [  # one 1984x2560 page through VGG16-BN (Cin >= 64 layers)
         ("c1_2 64->64 @1984x2560 p2x2", (1, 1984, 2560, 64, 3, 1, 64, 1, 1, 0)),
         ("c2_1 64->128 @992x1280", (1, 992, 1280, 64, 3, 1, 128, 0, 1, 0)),
