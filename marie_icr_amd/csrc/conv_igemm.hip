@@ -40,31 +40,34 @@ namespace {
 //   BN = 128, BM = 256: waves 4(M) x 2(N),  64x64 per wave, 3-slot ring of 48 KiB  (N <= 128)
 //   BN = 256, BM = 256: waves 2(M) x 4(N), 128x64 per wave, 2-slot ring of 64 KiB  (N  > 128): 1.5x fewer L2->LDS
 //             bytes and 25 % fewer LDS fragment reads per MFMA than the 128-wide tile.
+//   code 1128: BN = 128, BM = 128: waves 4(M) x 2(N), 32x64 per wave, 4-slot ring of 32 KiB — for GEMMs with so few rows
+//             (decoder steps: M = crops x beams) that the big tiles would leave most of the 256 CUs idle.
 template <int BN_>
 struct Cfg {
-  static constexpr int BN = BN_;
-  static constexpr int BM = (BN_ == 64) ? 512 : 256;
-  static constexpr int WN = BN_ / 64;            // waves along N
+  static constexpr bool SMALL = BN_ > 1000;
+  static constexpr int BN = BN_ % 1000;
+  static constexpr int BM = SMALL ? 128 : ((BN == 64) ? 512 : 256);
+  static constexpr int WN = BN / 64;             // waves along N
   static constexpr int WM = 8 / WN;              // waves along M
   static constexpr int MT = BM / WM / 16;        // 16-row MFMA tiles per wave along M (4 or 8)
 #ifdef IGEMM_KSPLIT
   // Explored variant (N tile 256): each K slice staged as two 64-byte half-rows (k-groups) in a 4-slot ring of 32 KiB
   // half-slices, so three half-slices (96 KiB) are in flight and a k-group's MFMAs start as soon as ITS half has
   // landed.  Measured 8-10 % SLOWER than the 2-slot whole-slice ring (twice the barriers; profiles/r01/h_*): off.
-  static constexpr bool KSPLIT = (BN_ == 256);
+  static constexpr bool KSPLIT = (BN == 256);
 #else
   static constexpr bool KSPLIT = false;
 #endif
-  static constexpr int NSTAGE = KSPLIT ? 4 : ((BN_ == 128) ? 3 : 2);
+  static constexpr int NSTAGE = (KSPLIT || SMALL) ? 4 : ((BN == 128) ? 3 : 2);
   static constexpr int HROWB = KSPLIT ? 64 : ROWB;        // bytes of one staged row
   static constexpr int A_BYTES = BM * HROWB;
-  static constexpr int B_BYTES = BN_ * HROWB;
+  static constexpr int B_BYTES = BN * HROWB;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int RPI = 64 * 16 / HROWB / 1;         // rows covered by one wave-instruction (8 or 16)
   static constexpr int ACHUNKS = BM * (HROWB / 16) / NTHREADS;   // A chunks staged per thread per (half-)slice
-  static constexpr int WCHUNKS = BN_ * (HROWB / 16) / NTHREADS;  // W chunks
+  static constexpr int WCHUNKS = BN * (HROWB / 16) / NTHREADS;   // W chunks
   static constexpr int GL = ACHUNKS + WCHUNKS;   // LDS-DMA instructions per wave per (half-)slice
-  static constexpr int EPW = BN_ < 128 ? BN_ : 128;       // output columns per epilogue pass
+  static constexpr int EPW = BN < 128 ? BN : 128;         // output columns per epilogue pass
   static constexpr int EPI_BYTES = BM * (EPW * 4 + 16);   // one epilogue pass, fp32 worst case
   static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
   static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
@@ -413,6 +416,23 @@ int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
   return 0;
 }
 
+// the small 128x128 tile: plain (unpooled, single-input) convs / GEMMs only
+template <typename T>
+int launch_small(mhip_ctx* ctx, const IgemmArgs& a) {
+  dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(NTHREADS);
+  const size_t lds = Cfg<1128>::LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, POOL_NONE, 1128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+              hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, 1128, false>), grid, block, lds, ctx->stream, a));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "conv_igemm launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
 }  // namespace
 
 double mhip_conv_flops(const ConvDesc& d) {
@@ -487,6 +507,12 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   const int bm = (bn == 64) ? 512 : 256;
   a.mtiles = (a.M + bm - 1) / bm;
   a.ntiles = (a.N + bn - 1) / bn;
+  // too few big tiles to occupy the 256 CUs (decoder-step GEMMs, heads on small maps): 128 x 128 tiles instead
+  if (a.mtiles * a.ntiles < 192 && a.N > 64 && d.pool == POOL_NONE && !d.in2) {
+    a.mtiles = (a.M + 127) / 128;
+    a.ntiles = (a.N + 127) / 128;
+    return precision == MHIP_PREC_F16 ? launch_small<_Float16>(ctx, a) : launch_small<float>(ctx, a);
+  }
   if (precision == MHIP_PREC_F16)
     return bn == 256 ? launch_t<_Float16, 256>(ctx, a, d.pool)
                      : (bn == 128 ? launch_t<_Float16, 128>(ctx, a, d.pool) : launch_t<_Float16, 64>(ctx, a, d.pool));
