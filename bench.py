@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["dit_trocr", "craft_crnn", "pages", "crnn"], default="dit_trocr")
-    ap.add_argument("--pages", type=int, default=0, help="pages per GPU per step (default: 16 dit_trocr, 12 craft_crnn)")
+    ap.add_argument("--pages", type=int, default=0, help="pages per GPU per step (default: 32 dit_trocr, 12 craft_crnn)")
     ap.add_argument("--det-batch", type=int, default=8, help="pages per detector forward (dit_trocr)")
     ap.add_argument("--decode-len", type=int, default=15, help="generated tokens before the forced EOS (dit_trocr)")
     ap.add_argument("--model", choices=["base", "large"], default="base", help="DiT detector size (dit_trocr)")
@@ -319,7 +319,7 @@ def main():
     if args.workload == "pages":
         args.workload = "craft_crnn"
     if args.pages <= 0:
-        args.pages = 16 if args.workload == "dit_trocr" else 12
+        args.pages = 32 if args.workload == "dit_trocr" else 12
 
     import torch
 

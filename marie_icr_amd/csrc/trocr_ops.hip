@@ -133,23 +133,31 @@ __global__ __launch_bounds__(64 * DA_WAVES) void decode_attn_kernel(DecAttnArgs 
 #pragma unroll
     for (int j = 0; j < EPC; ++j)
       q[qi][j] = (live && qi < p.nq) ? (float)((const T*)p.q)[(size_t)(row0 + qi) * p.ldq + h * 64 + c * EPC + j] : 0.f;
-  // scores: lanes of one key (CPR of them) each hold a partial dot product
+  // scores: lanes of one key (CPR of them) each hold a partial dot product; 4 keys in flight per lane
   if (live)
-    for (int s = ks; s < p.n_keys; s += KPI) {
-      const T* kr = (const T*)p.k + key_row(s) * p.ldk + h * 64 + c * EPC;
-      T kv[EPC];
-      *(uint4*)kv = *(const uint4*)kr;
-      float part[DA_MAXQ];
+    for (int s0 = ks; s0 < p.n_keys; s0 += 4 * KPI) {
+      T kv[4][EPC];
 #pragma unroll
-      for (int qi = 0; qi < DA_MAXQ; ++qi) {
-        part[qi] = 0.f;
-#pragma unroll
-        for (int j = 0; j < EPC; ++j) part[qi] += q[qi][j] * (float)kv[j];
-#pragma unroll
-        for (int o = 1; o < CPR; o <<= 1) part[qi] += __shfl_xor(part[qi], o);
+      for (int u = 0; u < 4; ++u) {
+        const int s = s0 + u * KPI;
+        if (s < p.n_keys) *(uint4*)kv[u] = *(const uint4*)((const T*)p.k + key_row(s) * p.ldk + h * 64 + c * EPC);
       }
-      if (c == 0)
-        for (int qi = 0; qi < p.nq; ++qi) sp[wave][qi][s] = part[qi];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = s0 + u * KPI;
+        if (s >= p.n_keys) break;
+        float part[DA_MAXQ];
+#pragma unroll
+        for (int qi = 0; qi < DA_MAXQ; ++qi) {
+          part[qi] = 0.f;
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) part[qi] += q[qi][j] * (float)kv[u][j];
+#pragma unroll
+          for (int o = 1; o < CPR; o <<= 1) part[qi] += __shfl_xor(part[qi], o);
+        }
+        if (c == 0)
+          for (int qi = 0; qi < p.nq; ++qi) sp[wave][qi][s] = part[qi];
+      }
     }
   __syncthreads();
   float inv[DA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
@@ -171,15 +179,23 @@ __global__ __launch_bounds__(64 * DA_WAVES) void decode_attn_kernel(DecAttnArgs 
   for (int qi = 0; qi < DA_MAXQ; ++qi)
 #pragma unroll
     for (int j = 0; j < EPC; ++j) acc[qi][j] = 0.f;
-  for (int s = ks; s < p.n_keys; s += KPI) {
-    const T* vr = (const T*)p.v + key_row(s) * p.ldk + h * 64 + c * EPC;
-    T vv[EPC];
-    *(uint4*)vv = *(const uint4*)vr;
+  for (int s0 = ks; s0 < p.n_keys; s0 += 4 * KPI) {
+    T vv[4][EPC];
 #pragma unroll
-    for (int qi = 0; qi < DA_MAXQ; ++qi) {
-      const float w = qi < p.nq ? sp[wave][qi][s] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u * KPI;
+      if (s < p.n_keys) *(uint4*)vv[u] = *(const uint4*)((const T*)p.v + key_row(s) * p.ldk + h * 64 + c * EPC);
+    }
 #pragma unroll
-      for (int j = 0; j < EPC; ++j) acc[qi][j] += w * (float)vv[j];
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u * KPI;
+      if (s >= p.n_keys) break;
+#pragma unroll
+      for (int qi = 0; qi < DA_MAXQ; ++qi) {
+        const float w = qi < p.nq ? sp[wave][qi][s] : 0.f;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) acc[qi][j] += w * (float)vv[u][j];
+      }
     }
   }
 #pragma unroll
@@ -217,7 +233,7 @@ struct CandArgs {
   int* cand_beams;        // [bsz][2*beam]
 };
 
-constexpr int CAND_T = 1024, CAND_K = 8;   // per-thread shortlist
+constexpr int CAND_T = 1024, CAND_K = 8;   // per-thread shortlist length (>= 2 * beam)
 
 // one workgroup per crop
 __global__ __launch_bounds__(CAND_T) void beam_candidates_kernel(CandArgs p) {
@@ -271,25 +287,39 @@ __global__ __launch_bounds__(CAND_T) void beam_candidates_kernel(CandArgs p) {
       }
     }
   }
+  // K rounds of "largest key in the wave" (each lane's shortlist is sorted, so its head is its best remaining key),
+  // then wave 0 repeats that over the 16 wave winners' lists — no sort of the 8192 shortlisted keys.
+  {
+    int head = 0;
+    for (int r = 0; r < K; ++r) {
+      const u64 mine = head < K ? best[head] : 0ull;
+      u64 mx = mine;
 #pragma unroll
-  for (int j = 0; j < CAND_K; ++j) keys[tid * CAND_K + j] = j < K ? best[j] : 0;
-  // bitonic sort (descending) of CAND_T * CAND_K keys
-  const int n = CAND_T * CAND_K;
-  for (int k = 2; k <= n; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
-      for (int i = tid; i < n; i += CAND_T) {
-        const int l = i ^ j;
-        if (l > i) {
-          const u64 x = keys[i], y = keys[l];
-          const bool up = (i & k) == 0;
-          if (up ? (x < y) : (x > y)) { keys[i] = y; keys[l] = x; }
-        }
-      }
+      for (int o = 32; o; o >>= 1) { const u64 other = __shfl_xor(mx, o); mx = other > mx ? other : mx; }
+      if (mine == mx && mx != 0ull) ++head;            // keys are unique (they embed the flat index)
+      if (lane == 0) keys[wv * CAND_K + r] = mx;
     }
+  }
+  __syncthreads();
+  if (wv == 0) {
+    u64 mine[4];                                         // 16 waves x K <= 128 keys: lane holds up to 2 (K <= 8)
+    const int total = 16 * K;
+    int cnt = 0;
+    for (int e = lane; e < total; e += 64) mine[cnt++] = keys[(e / K) * CAND_K + (e % K)];
+    for (int r = 0; r < K; ++r) {
+      u64 m = 0ull;
+      for (int e = 0; e < cnt; ++e) m = mine[e] > m ? mine[e] : m;
+      u64 mx = m;
+#pragma unroll
+      for (int o = 32; o; o >>= 1) { const u64 other = __shfl_xor(mx, o); mx = other > mx ? other : mx; }
+      for (int e = 0; e < cnt; ++e)
+        if (mine[e] == mx) mine[e] = 0ull;
+      if (lane == 0) keys[1024 + r] = mx;
+    }
+  }
   __syncthreads();
   if (tid < K) {
-    const u64 c = keys[tid];
+    const u64 c = keys[1024 + tid];
     const unsigned flat = 0xffffffffu - (unsigned)(c & 0xffffffffu);
     p.cand_scores[sample * K + tid] = okey_inv((unsigned)(c >> 32));
     p.cand_tokens[sample * K + tid] = (int)(flat % (unsigned)p.vocab);
@@ -354,7 +384,7 @@ int mhip_launch_beam_candidates(mhip_ctx* ctx, const BeamCandDesc& d) {
   a.logits = d.logits; a.ld = d.ld; a.vocab = d.vocab; a.beam = d.beam; a.cum = d.cum; a.step = d.step;
   a.max_len = d.max_len; a.min_len = d.min_len; a.pad = d.pad; a.eos = d.eos;
   a.cand_scores = d.cand_scores; a.cand_tokens = d.cand_tokens; a.cand_beams = d.cand_beams;
-  const int lds = CAND_T * CAND_K * 8;
+  const int lds = (1024 + 64) * 8;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)beam_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
