@@ -53,13 +53,14 @@ def broadcast_arena(model, ctx, dist, src: int = 0) -> None:
     torch.cuda.synchronize()
 
 
-def broadcast_arenas(model, ctx, dist, src: int = 0) -> None:
+def broadcast_arenas(model, ctx, dist, src: int = 0, device: str = "cuda") -> None:
     """Same as :func:`broadcast_arena` for models that keep several arenas (``model.arenas()`` -> [(ptr, bytes), ...]:
-    the DiT detector and TrOCR keep the ViT encoder and the heads / decoder apart)."""
+    the DiT detector and TrOCR keep the ViT encoder and the heads / decoder apart).  ``device="cpu"`` is the gloo
+    rehearsal path of the tests (``ctx.memcpy_dev`` then copies between host buffers)."""
     import torch
 
     for ptr, nbytes in model.arenas():
-        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         if dist.get_rank() == src:
             ctx.memcpy_dev(buf.data_ptr(), ptr, nbytes)
             ctx.synchronize()
@@ -67,4 +68,5 @@ def broadcast_arenas(model, ctx, dist, src: int = 0) -> None:
         if dist.get_rank() != src:
             ctx.memcpy_dev(ptr, buf.data_ptr(), nbytes)
         ctx.synchronize()
-    torch.cuda.synchronize()
+    if device == "cuda":
+        torch.cuda.synchronize()

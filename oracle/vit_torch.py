@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 
 def _t(a):
-    return torch.from_numpy(np.ascontiguousarray(a))
+    return torch.from_numpy(np.array(a, copy=True, order="C"))
 
 
 class TorchVitOracle:

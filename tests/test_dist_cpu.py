@@ -48,3 +48,66 @@ def test_two_rank_gather_restores_page_order():
     for rank, pages, ranks in got:
         assert pages == list(range(n_items))
         assert ranks == [i % 2 for i in range(n_items)]
+
+
+class _HostCtx:
+    """stands in for marie_icr_amd._lib.Context in the gloo rehearsal: "device" memory is host memory"""
+
+    def memcpy_dev(self, dst, src, n):
+        import ctypes
+
+        ctypes.memmove(dst, src, n)
+
+    def synchronize(self):
+        pass
+
+
+class _TwoArenaModel:
+    """like DitModel / TrocrModel: two packed weight arenas"""
+
+    def __init__(self, fill):
+        import numpy as np
+
+        self.a = [np.full(1 << 16, fill, np.uint8), np.full(12345, fill, np.uint8)]
+
+    def arenas(self):
+        return [(x.ctypes.data, x.nbytes) for x in self.a]
+
+
+def _bcast_worker(rank, world, port, q):
+    import numpy as np
+    import torch.distributed as dist
+
+    from marie_icr_amd.dist import broadcast_arenas, shard_indices
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _TwoArenaModel(0)
+    if rank == 0:                       # rank 0 "packed the weights"
+        rng = np.random.default_rng(7)
+        for x in m.a:
+            x[:] = rng.integers(0, 256, x.shape, dtype=np.uint8)
+    broadcast_arenas(m, _HostCtx(), dist, src=0, device="cpu")
+    pages = shard_indices(9, rank, world)      # bench.py's page partition of a 9-page job
+    q.put((rank, [int(x.sum()) for x in m.a], pages))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_weight_arena_broadcast():
+    """the start-up collective of bench.py --workload dit_trocr (RCCL there, gloo here)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (sums, pages)) for r, sums, pages in [q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] and got[0][0][0] > 0
+    assert sorted(got[0][1] + got[1][1]) == list(range(9))

@@ -105,3 +105,38 @@ def test_engine_full_page_vs_oracle(ctx):
     ok = eng.extract(pages[:1], PSMode.RAW_LINE, CoordinateFormat.XYWH,
                      regions=[{"id": 7, "pageIndex": 0, "x": 10, "y": 20, "w": 120, "h": 30}])
     assert [r["id"] for r in ok["regions"]] == [7] and isinstance(ok["regions"][0]["text"], str)
+
+
+def test_engine_with_dit_detector_and_trocr_recognizer(ctx):
+    """The production wiring (BoxProcessorUlimDit + TrOcrProcessor) behind OcrEngine.extract: structure of the result,
+    word/box/line bookkeeping, and text = what the recognizer returns for each fragment of the box processor."""
+    from marie_icr_amd.box_processor import PSMode
+    from marie_icr_amd.dit import default_config as dit_config
+    from marie_icr_amd.dit_box_processor import BoxProcessorUlimDit
+    from marie_icr_amd.ocr_engine import CoordinateFormat, MarieHipOcrEngine
+    from marie_icr_amd.trocr import TrOcrProcessor, default_config as trocr_config
+    from marie_icr_amd.weights import make_dit_state, make_image_u8, make_trocr_state
+
+    dcfg = dit_config(ctx.lib, "base")
+    dcfg.min_size_test, dcfg.max_size_test = 160, 400
+    enc, dec = (256, 2, 4), (256, 2, 4, 512)
+    tcfg = trocr_config(ctx.lib, "base")
+    tcfg.enc_dim, tcfg.enc_depth, tcfg.enc_heads = enc
+    tcfg.dec_dim, tcfg.dec_layers, tcfg.dec_heads, tcfg.dec_ffn = dec
+    tcfg.vocab, tcfg.max_positions, tcfg.max_len_b = 97, 32, 8
+    box = BoxProcessorUlimDit(cuda=True, state=make_dit_state(0), model="base", precision="f16", ctx=ctx, config=dcfg,
+                              refinement=False)
+    rec = TrOcrProcessor(state=make_trocr_state(0, enc, dec, 97, 32), config=tcfg, precision="f16", ctx=ctx)
+    eng = MarieHipOcrEngine(box_processor=box, default_ocr_processor=rec)
+    page = make_image_u8(11, 1, 330, 255)[0]
+    res = eng.extract([page], PSMode.SPARSE, CoordinateFormat.XYWH)
+    assert len(res) == 1
+    words, lines = res[0]["words"], res[0]["lines"]
+    rects, frags, numbers, _, line_boxes = box.extract_bounding_boxes("t", "k", page, PSMode.SPARSE)
+    assert len(words) == len(rects) > 5
+    assert sorted(tuple(int(v) for v in w["box"]) for w in words) == sorted(tuple(int(v) for v in r) for r in rects)
+    texts = {r["text"] for r in rec.recognize_from_fragments(frags)}
+    assert {w["text"] for w in words} <= texts
+    assert all(0.0 <= w["confidence"] <= 1.0 for w in words)
+    assert {w["line"] for w in words} == {ln["line"] for ln in lines}
+    assert len(line_boxes) >= 1
