@@ -271,3 +271,6 @@ struct BeamCandDesc {
 };
 int mhip_launch_beam_candidates(mhip_ctx* ctx, const BeamCandDesc& d);
 int mhip_launch_ancestry(mhip_ctx* ctx, const int* anc_old, int* anc_new, const int* parent, int rows, int ld, int step);
+size_t mhip_pil_resize_fragments_scratch(const mhip_crop_desc* descs, int n, int dh, int dw, int filter);
+int mhip_pil_resize_fragments(mhip_ctx* ctx, const uint8_t* base_dev, const mhip_crop_desc* descs, int n, uint8_t* dst, int dh,
+                              int dw, int filter, void* scratch, size_t scratch_bytes);

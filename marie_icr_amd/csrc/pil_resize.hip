@@ -11,6 +11,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -105,6 +106,92 @@ __global__ __launch_bounds__(256) void pil_vpass_kernel(const uint8_t* __restric
   }
 }
 
+// ---- batched variant: n fragments of different sizes -> n images of one size, one launch per pass -------------------
+struct FragDev {
+  unsigned long long src_off;   // byte offset of the fragment's first pixel
+  unsigned long long tmp_off;   // byte offset of its [h][dw][3] intermediate
+  int h, w, row_stride;
+};
+
+// coefficient tables of all fragments: axis 0 = x (in_size = w), axis 1 = y (in_size = h); kmax taps per output
+__global__ void pil_coeffs_batch_kernel(const FragDev* __restrict__ fr, int axis, int out_size, int filter, int kmax,
+                                        int* __restrict__ bounds, int* __restrict__ kk) {
+  const int f = blockIdx.y, xx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xx >= out_size) return;
+  const int in_size = axis ? fr[f].h : fr[f].w;
+  const double scale = (double)in_size / (double)out_size;
+  double filterscale = scale;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = (filter == MHIP_PIL_BILINEAR ? 1.0 : 2.0) * filterscale;
+  const double center = ((double)xx + 0.5) * scale;
+  const double ss = 1.0 / filterscale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  double ww = 0.0;
+  for (int x = 0; x < xmax; ++x) ww += filt(filter, ((double)(x + xmin) - center + 0.5) * ss);
+  int* k = kk + ((size_t)f * out_size + xx) * kmax;
+  for (int x = 0; x < kmax; ++x) {
+    int v = 0;
+    if (x < xmax) {
+      double w = filt(filter, ((double)(x + xmin) - center + 0.5) * ss);
+      if (ww != 0.0) w /= ww;
+      v = w < 0 ? (int)(-0.5 + w * (double)(1 << PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << PRECISION_BITS));
+    }
+    k[x] = v;
+  }
+  bounds[((size_t)f * out_size + xx) * 2] = xmin;
+  bounds[((size_t)f * out_size + xx) * 2 + 1] = xmax;
+}
+
+__global__ __launch_bounds__(256) void pil_hpass_batch_kernel(const uint8_t* __restrict__ base, const FragDev* __restrict__ fr,
+                                                              int dw, int kmax, const int* __restrict__ bounds,
+                                                              const int* __restrict__ kk, uint8_t* __restrict__ tmp) {
+  const FragDev d = fr[blockIdx.y];
+  const int total = d.h * dw;
+  const int* bb = bounds + (size_t)blockIdx.y * dw * 2;
+  const int* kf = kk + (size_t)blockIdx.y * dw * kmax;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int yy = i / dw, xx = i - yy * dw;
+    const int xmin = bb[2 * xx], n = bb[2 * xx + 1];
+    const int* k = kf + (size_t)xx * kmax;
+    const uint8_t* p = base + d.src_off + (size_t)yy * d.row_stride + (size_t)xmin * 3;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    for (int x = 0; x < n; ++x) {
+      const int w = k[x];
+      a0 += (int)p[3 * x] * w; a1 += (int)p[3 * x + 1] * w; a2 += (int)p[3 * x + 2] * w;
+    }
+    uint8_t* o = tmp + d.tmp_off + (size_t)i * 3;
+    o[0] = clip8(a0); o[1] = clip8(a1); o[2] = clip8(a2);
+  }
+}
+
+__global__ __launch_bounds__(256) void pil_vpass_batch_kernel(const uint8_t* __restrict__ tmp, const FragDev* __restrict__ fr,
+                                                              int dw, int dh, int kmax, const int* __restrict__ bounds,
+                                                              const int* __restrict__ kk, uint8_t* __restrict__ dst) {
+  const FragDev d = fr[blockIdx.y];
+  const int total = dh * dw;
+  const int* bb = bounds + (size_t)blockIdx.y * dh * 2;
+  const int* kf = kk + (size_t)blockIdx.y * dh * kmax;
+  uint8_t* out = dst + (size_t)blockIdx.y * total * 3;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int yy = i / dw, xx = i - yy * dw;
+    const int ymin = bb[2 * yy], n = bb[2 * yy + 1];
+    const int* k = kf + (size_t)yy * kmax;
+    const uint8_t* p = tmp + d.tmp_off + ((size_t)ymin * dw + xx) * 3;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    for (int y = 0; y < n; ++y) {
+      const int w = k[y];
+      const uint8_t* q = p + (size_t)y * dw * 3;
+      a0 += (int)q[0] * w; a1 += (int)q[1] * w; a2 += (int)q[2] * w;
+    }
+    uint8_t* o = out + (size_t)i * 3;
+    o[0] = clip8(a0); o[1] = clip8(a1); o[2] = clip8(a2);
+  }
+}
+
 int ksize_of(int in_size, int out_size, int filter) {
   double scale = (double)in_size / (double)out_size;
   if (scale < 1.0) scale = 1.0;
@@ -143,6 +230,60 @@ int mhip_launch_pil_resize_rgb(mhip_ctx* ctx, const uint8_t* src, int sh, int sw
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "pil_resize launch: %s", hipGetErrorString(e));
   return 0;
+}
+
+// n fragments (3-channel u8, descs on the host) -> dst [n][dh][dw][3].  Allocates its scratch from the context workspace
+// TAIL (offset ws_off onwards), so callers that carve the head of the workspace are not disturbed.
+int mhip_pil_resize_fragments(mhip_ctx* ctx, const uint8_t* base_dev, const mhip_crop_desc* descs, int n, uint8_t* dst, int dh,
+                              int dw, int filter, void* scratch, size_t scratch_bytes) {
+  if (n < 1) return 0;
+  std::vector<FragDev> fr(n);
+  size_t tmp_total = 0;
+  int kx = 1, ky = 1, hmax = 1;
+  for (int i = 0; i < n; ++i) {
+    if (descs[i].channels != 3 || descs[i].h < 1 || descs[i].w < 1) return mhip_fail(ctx, MHIP_EINVAL, "pil_resize: fragment %d must be h x w x 3", i);
+    fr[i].src_off = descs[i].src_offset; fr[i].tmp_off = tmp_total;
+    fr[i].h = descs[i].h; fr[i].w = descs[i].w; fr[i].row_stride = descs[i].row_stride;
+    tmp_total += ((size_t)descs[i].h * dw * 3 + 255) / 256 * 256;
+    kx = std::max(kx, ksize_of(descs[i].w, dw, filter));
+    ky = std::max(ky, ksize_of(descs[i].h, dh, filter));
+    hmax = std::max(hmax, descs[i].h);
+  }
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t need = al(n * sizeof(FragDev)) + al(tmp_total) + al((size_t)n * dw * 8) + al((size_t)n * dw * kx * 4) +
+                      al((size_t)n * dh * 8) + al((size_t)n * dh * ky * 4);
+  if (need > scratch_bytes) return mhip_fail(ctx, MHIP_ENOMEM, "pil_resize: scratch %zu < %zu", scratch_bytes, need);
+  char* p = (char*)scratch;
+  FragDev* dfr = (FragDev*)p; p += al(n * sizeof(FragDev));
+  uint8_t* tmp = (uint8_t*)p; p += al(tmp_total);
+  int* bx = (int*)p; p += al((size_t)n * dw * 8);
+  int* kkx = (int*)p; p += al((size_t)n * dw * kx * 4);
+  int* by = (int*)p; p += al((size_t)n * dh * 8);
+  int* kky = (int*)p;
+  MHIP_HIP(ctx, hipMemcpyAsync(dfr, fr.data(), n * sizeof(FragDev), hipMemcpyHostToDevice, ctx->stream));
+  MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // fr is a host temporary
+  PROF_LAUNCH(ctx, MHIP_K_IMAGE_OPS, {
+    hipLaunchKernelGGL(pil_coeffs_batch_kernel, dim3((dw + 255) / 256, n), dim3(256), 0, ctx->stream, dfr, 0, dw, filter, kx, bx, kkx);
+    hipLaunchKernelGGL(pil_coeffs_batch_kernel, dim3((dh + 255) / 256, n), dim3(256), 0, ctx->stream, dfr, 1, dh, filter, ky, by, kky);
+    hipLaunchKernelGGL(pil_hpass_batch_kernel, dim3((hmax * dw + 255) / 256, n), dim3(256), 0, ctx->stream, base_dev, dfr, dw, kx, bx, kkx, tmp);
+    hipLaunchKernelGGL(pil_vpass_batch_kernel, dim3((dh * dw + 255) / 256, n), dim3(256), 0, ctx->stream, tmp, dfr, dw, dh, ky, by, kky, dst);
+  });
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "pil_resize_fragments launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+size_t mhip_pil_resize_fragments_scratch(const mhip_crop_desc* descs, int n, int dh, int dw, int filter) {
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  size_t tmp_total = 0;
+  int kx = 1, ky = 1;
+  for (int i = 0; i < n; ++i) {
+    tmp_total += ((size_t)std::max(descs[i].h, 1) * dw * 3 + 255) / 256 * 256;
+    kx = std::max(kx, ksize_of(std::max(descs[i].w, 1), dw, filter));
+    ky = std::max(ky, ksize_of(std::max(descs[i].h, 1), dh, filter));
+  }
+  return al(n * sizeof(FragDev)) + al(tmp_total) + al((size_t)n * dw * 8) + al((size_t)n * dw * kx * 4) + al((size_t)n * dh * 8) +
+         al((size_t)n * dh * ky * 4) + 4096;
 }
 
 // replaces: Image.fromarray(rgb).resize((dw, dh), BILINEAR | BICUBIC) on host buffers (test / standalone entry)

@@ -24,6 +24,11 @@ struct mhip_trocr {
   TensorStore store;
   Arena arena;
   bool ready = false;
+  // grow-only staging of generate_fragments (resized crops + resize scratch): no hipMalloc in steady state
+  uint8_t* frag_crops = nullptr;
+  size_t frag_crops_bytes = 0;
+  void* frag_scratch = nullptr;
+  size_t frag_scratch_bytes = 0;
   size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
 };
 
@@ -90,6 +95,8 @@ extern "C" int mhip_trocr_destroy(mhip_trocr* m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   mhip_vit_destroy(m->vit);
   m->arena.release();
+  if (m->frag_crops) (void)hipFree(m->frag_crops);
+  if (m->frag_scratch) (void)hipFree(m->frag_scratch);
   delete m;
   return MHIP_OK;
 }
@@ -443,22 +450,24 @@ extern "C" int mhip_trocr_generate_fragments(mhip_trocr* m, const uint8_t* base_
   mhip_ctx* ctx = m->ctx;
   MHIP_HIP(ctx, hipSetDevice(ctx->device));
   const int S = m->cfg.img_size;
-  size_t scratch = 0;
-  for (int i = 0; i < n; ++i) {
-    if (descs_host[i].channels != 3 || descs_host[i].h < 1 || descs_host[i].w < 1) return mhip_fail(ctx, MHIP_EINVAL, "trocr: fragment %d must be h x w x 3", i);
-    scratch = std::max(scratch, mhip_pil_resize_scratch_bytes(descs_host[i].h, descs_host[i].w, S, S, MHIP_PIL_BICUBIC));
+  const size_t scratch = mhip_pil_resize_fragments_scratch(descs_host, n, S, S, MHIP_PIL_BICUBIC);
+  const size_t cb = (size_t)n * S * S * 3;
+  if (cb > m->frag_crops_bytes || scratch > m->frag_scratch_bytes) {
+    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (cb > m->frag_crops_bytes) {
+      if (m->frag_crops) (void)hipFree(m->frag_crops);
+      m->frag_crops = nullptr; m->frag_crops_bytes = 0;
+      MHIP_HIP(ctx, hipMalloc((void**)&m->frag_crops, cb));
+      m->frag_crops_bytes = cb;
+    }
+    if (scratch > m->frag_scratch_bytes) {
+      if (m->frag_scratch) (void)hipFree(m->frag_scratch);
+      m->frag_scratch = nullptr; m->frag_scratch_bytes = 0;
+      MHIP_HIP(ctx, hipMalloc(&m->frag_scratch, scratch));
+      m->frag_scratch_bytes = scratch;
+    }
   }
-  uint8_t* crops = nullptr;
-  void* sc = nullptr;
-  MHIP_HIP(ctx, hipMalloc((void**)&crops, (size_t)n * S * S * 3));
-  if (hipMalloc(&sc, scratch) != hipSuccess) { (void)hipFree(crops); return mhip_fail(ctx, MHIP_ENOMEM, "trocr: resize scratch"); }
-  int rc = MHIP_OK;
-  for (int i = 0; i < n && !rc; ++i)
-    rc = mhip_launch_pil_resize_rgb(ctx, base_dev + descs_host[i].src_offset, descs_host[i].h, descs_host[i].w,
-                                    (size_t)descs_host[i].row_stride, crops + (size_t)i * S * S * 3, S, S, MHIP_PIL_BICUBIC, sc);
-  if (!rc) rc = trocr_generate(m, crops, n, swap_rb, tokens_out, lengths_out, scores_out, nullptr, nullptr);
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(sc);
-  (void)hipFree(crops);
+  int rc = mhip_pil_resize_fragments(ctx, base_dev, descs_host, n, m->frag_crops, S, S, MHIP_PIL_BICUBIC, m->frag_scratch, m->frag_scratch_bytes);
+  if (!rc) rc = trocr_generate(m, m->frag_crops, n, swap_rb, tokens_out, lengths_out, scores_out, nullptr, nullptr);
   return rc;
 }
