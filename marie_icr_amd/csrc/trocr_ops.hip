@@ -133,8 +133,41 @@ __global__ __launch_bounds__(64 * DA_WAVES) void decode_attn_kernel(DecAttnArgs 
 #pragma unroll
     for (int j = 0; j < EPC; ++j)
       q[qi][j] = (live && qi < p.nq) ? (float)((const T*)p.q)[(size_t)(row0 + qi) * p.ldq + h * 64 + c * EPC + j] : 0.f;
-  // scores: lanes of one key (CPR of them) each hold a partial dot product; 4 keys in flight per lane
-  if (live)
+  // scores.  f16: Q K^T on the matrix core — the group's queries are rows 0..nq-1 of a 16-row A tile (other rows zero),
+  // 16 keys are the columns of the B tile, so a wave-instruction streams 16 keys x 64 bytes and the scores of those keys
+  // land in lanes 0..15 (accumulator rows 0..3): no cross-lane reduction, no FMAs.  fp32: lanes of one key hold partial
+  // dot products (CPR lanes per key), reduced with shuffles.
+  if (live && sizeof(T) == 2) {
+    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+    const int n = lane & 15, g = lane >> 4;
+    half8v qa[2];
+#pragma unroll
+    for (int kstep = 0; kstep < 2; ++kstep)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        qa[kstep][j] = n < p.nq ? ((const _Float16*)p.q)[(size_t)(row0 + n) * p.ldq + h * 64 + kstep * 32 + g * 8 + j] : (_Float16)0.f;
+    for (int s0 = 0; s0 < p.n_keys; s0 += 32) {           // two 16-key tiles in flight
+      half8v kb[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int s = min(s0 + t * 16 + n, p.n_keys - 1);   // clamp: columns past the end are never stored
+        const _Float16* kr = (const _Float16*)p.k + key_row(s) * p.ldk + h * 64 + g * 8;
+        kb[t][0] = *(const half8v*)kr;
+        kb[t][1] = *(const half8v*)(kr + 32);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float4v c4 = {0.f, 0.f, 0.f, 0.f};
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[0], kb[t][0], c4, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[1], kb[t][1], c4, 0, 0, 0);
+        const int s = s0 + t * 16 + n;
+        if (g == 0 && s < p.n_keys)
+#pragma unroll
+          for (int qi = 0; qi < DA_MAXQ; ++qi)
+            if (qi < p.nq) sp[wave][qi][s] = c4[qi];
+      }
+    }
+  } else if (live)
     for (int s0 = ks; s0 < p.n_keys; s0 += 4 * KPI) {
       T kv[4][EPC];
 #pragma unroll
