@@ -240,10 +240,14 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
         for c in ctxs:
             c.profile_reset()
             c.profile_enable(True)
+        tA = time.perf_counter()
         detect_all()
         torch.cuda.synchronize()
+        tB = time.perf_counter()
         recognize_all()
         fence()
+        tC = time.perf_counter()
+        alone_ms = {"detector_ms_per_step_alone": 1e3 * (tB - tA), "recognizer_ms_per_step_alone": 1e3 * (tC - tB)}
         prof = {}
         for c in ctxs:
             for name, v in c.profile_read().items():
@@ -290,6 +294,7 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
                                      "peak": peak, "unit": "TFLOP/s", "algorithmic_gflop_per_step": a["flops"] / 1e9}
         out["kernels_ms_per_step"] = {n: v["total_ms"] for n, v in prof.items() if v["launches"]}
         out["kernel_ms_over_wall_ms"] = sum(out["kernels_ms_per_step"].values()) / (1e3 * dt / args.steps)
+        out.update(alone_ms)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_dit_trocr(dit_state, trocr_state, dims, args.decode_len, LINES_PER_PAGE)
     out["sample_output"] = [[int(t) for t in last[0][0][0]], last[0][0][1]] if last[0] else None

@@ -180,7 +180,8 @@ struct AttnDesc {
   void* out = nullptr;        // [images*npad_q][ldo] T
   int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
   int images = 0, heads = 0;
-  int npad_q = 0, npad_k = 0;  // rows per image (npad_q % 128 == 0, npad_k % 64 == 0)
+  int npad_q = 0, npad_k = 0;  // rows per image (npad_k % 8 == 0).  The last 128-query block / 64-key tile of an image may
+                               // read up to 127 rows past it: q, k need that many finite rows of slack, vt 64 elements
   int n_queries = 0, n_keys = 0;
 };
 int mhip_launch_attention(mhip_ctx* ctx, int precision, const AttnDesc& d);

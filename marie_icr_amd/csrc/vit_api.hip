@@ -245,7 +245,7 @@ void vit_geometry(const mhip_vit* m, int H32, int W32, VitGeom* g) {
   g->wp = W32 / m->cfg.patch;
   g->np = g->hp * g->wp;
   g->n_tok = g->np + 1;
-  g->npad = (g->n_tok + 127) / 128 * 128;
+  g->npad = (g->n_tok + 7) / 8 * 8;      // 16-byte aligned V^T columns per image; tiles may run into the next image's rows
 }
 
 size_t vit_workspace_bytes(const mhip_vit* m, int B, const VitGeom& g) {
@@ -254,8 +254,8 @@ size_t vit_workspace_bytes(const mhip_vit* m, int B, const VitGeom& g) {
   auto add = [&](size_t n) { b += (n + 255) / 256 * 256; };
   add(R * D * 4);              // x
   add(R * D * es);             // ln / attention output
-  add(R * 2 * D * es);         // q | k
-  add(D * R * es);             // v^T
+  add((R + 128) * 2 * D * es); // q | k (+ slack: the last image's final query block / key tile reads past its rows)
+  add((D * R + 128) * es);     // v^T (+ slack)
   add(R * D * es);             // attention output
   add(R * 4 * D * es);         // mlp hidden; also the patch matrix
   if (m->cfg.fpn) add(4 * (size_t)B * g.np * D * es);
@@ -287,8 +287,11 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
   const size_t R = (size_t)B * g.npad;
   float* x = ws.take<float>(R * D * 4);
   char* ln = ws.take(R * D * es);
-  char* qk = ws.take(R * 2 * D * es);
-  char* vt = ws.take(D * R * es);
+  char* qk = ws.take((R + 128) * 2 * D * es);
+  char* vt = ws.take((D * R + 128) * es);
+  // rows / columns past the last image are read by its final tiles (and masked): keep them finite
+  MHIP_HIP(ctx, hipMemsetAsync(qk + R * 2 * D * es, 0, (size_t)128 * 2 * D * es, ctx->stream));
+  MHIP_HIP(ctx, hipMemsetAsync(vt + (size_t)D * R * es, 0, 128 * es, ctx->stream));
   char* ao = ws.take(R * D * es);
   char* hid = ws.take(R * 4 * D * es);
   run->x = x;

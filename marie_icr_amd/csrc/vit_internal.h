@@ -17,7 +17,7 @@ struct mhip_vit {
 struct VitGeom {
   int hp, wp, np;   // patch grid
   int n_tok;        // 1 + np
-  int npad;         // rows per image (multiple of 128)
+  int npad;         // rows per image (multiple of 8)
 };
 
 struct VitRun {

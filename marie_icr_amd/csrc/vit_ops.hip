@@ -5,7 +5,7 @@
 // nn.LayerNorm (:293,305), PatchEmbed's patch gather + bicubic pos-emb resize (:362-376), and the token -> NCHW tap
 // reshape of forward_features (:730-732).  (GEMMs — qkv, proj, fc1, fc2, patch projection — are conv_igemm.hip.)
 //
-// Token layout: every image owns `npad` consecutive rows (npad % 128 == 0): row 0 = cls, rows 1..n_tok-1 = patches,
+// Token layout: every image owns `npad` consecutive rows (npad % 8 == 0): row 0 = cls, rows 1..n_tok-1 = patches,
 // the rest padding (finite values, masked as keys).  The residual stream is fp32; GEMM operands are T (f16 / fp32).
 //
 // attention (f16): one workgroup = 128 queries of one (image, head): 4 waves x 32 queries.  It is computed TRANSPOSED
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     const float inv = 1.f / l;
+    if (qb * AT_QB + wave * 32 + qt * 16 + n >= p.npad_q) continue;   // the last block may reach into the next image
     char* orow = p.out + ((qrow0 + qt * 16 + n) * p.ldo + h * HD) * 2;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -432,8 +433,8 @@ int mhip_launch_layernorm(mhip_ctx* ctx, int precision, const float* x, const fl
 }
 
 int mhip_launch_attention(mhip_ctx* ctx, int precision, const AttnDesc& d) {
-  if (d.images <= 0 || d.heads <= 0 || d.n_keys <= 0 || d.n_queries <= 0 || d.npad_q % AT_QB || d.npad_k % AT_KT ||
-      d.n_queries > d.npad_q || d.n_keys > d.npad_k)
+  if (d.images <= 0 || d.heads <= 0 || d.n_keys <= 0 || d.n_queries <= 0 || d.npad_k % 8 || d.n_queries > d.npad_q ||
+      d.n_keys > d.npad_k)
     return mhip_fail(ctx, MHIP_EINVAL, "attention: bad shape (q %d/%d, k %d/%d)", d.n_queries, d.npad_q, d.n_keys, d.npad_k);
   const int esz = precision == MHIP_PREC_F16 ? 2 : 4;
   if ((d.ldq * esz) % 16 || (d.ldk * esz) % 16 || (d.ldv * esz) % 16 || (d.ldo * esz) % 8)
