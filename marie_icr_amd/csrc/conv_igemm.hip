@@ -271,110 +271,110 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   if (acc[0][0][0] == 123.456f) *(float*)p.out = acc[1][1][1];
   return;
 #endif
-  // ---- epilogue: scale/bias, activation, in-register max-pool -> LDS (fp32) -> coalesced NHWC stores ----
-  // Staging is ALWAYS fp32: one ds_write_b32 per value, every lane its own bank.  (Staging f16 put two lanes into each
-  // dword; those sub-dword writes cost ~56 cycles per wave-instruction and made the epilogue 30 us per tile — more than
-  // the whole K = 768 main loop.  profiles/r01/i_epilogue.txt.)  Done in passes of 128 output columns.
+  // ---- epilogue: scale/bias, activation, in-register max-pool -> wave-private LDS transpose -> coalesced NHWC stores ----
+  // Each wave transposes its own 16-row x 64-column MFMA row-tile through a private 4 KiB fp32 staging area: 16
+  // conflict-free ds_write_b32 (one per accumulator value) and then 16-byte reads of 4 consecutive columns of one row,
+  // so a wave store covers 4 rows x 128 contiguous bytes (f16).  No workgroup barrier after the one that ends the main
+  // loop, all 8 waves busy.  (History: staging the whole 256x128 tile with half the waves idle and two barriers per pass
+  // cost 5 us per tile; before that an inlined erf-GELU made the epilogue instruction-fetch bound — profiles/r01/i_*.)
   constexpr int PF = (POOL == POOL_2x2) ? 4 : (POOL == POOL_2x1) ? 2 : 1;
-  constexpr int RQ = BM / PF;  // output rows of this tile
+  constexpr int RT = 16 / PF;          // staged rows per MFMA row-tile
+  constexpr int SPW = 64 * 4 + 16;     // staged row pitch in bytes (272: rows 4 apart land 16 banks apart)
   const int Mq = p.M / PF;
-  const int q0 = m0 / PF;
   const int oe = p.out_f32 ? 4 : (int)sizeof(T);
-  constexpr int EPW = C::EPW;
-  constexpr int SP = EPW * 4 + 16;     // staged row pitch in bytes
   const size_t grow = (size_t)(p.ldc ? p.ldc : p.N) * oe;  // global bytes per output pixel
-  // ReLU without a residual is applied here (branch-free); with a residual it follows the add, and GELU is applied in
-  // the copy-out loop — a ROLLED loop, so erff is inlined 8 times, not once per accumulator register (128 copies of it
-  // made this kernel 160 KB of code and the epilogue instruction-fetch bound).
-  const float lo = (p.relu == ACT_RELU && !p.res) ? 0.f : -INFINITY;
+  const float lo = (p.relu == ACT_RELU && !p.res) ? 0.f : -INFINITY;   // ReLU without a residual: here, branch-free
+  const float lo2 = (p.relu == ACT_RELU && p.res) ? 0.f : -INFINITY;   // with a residual: after the add
   const bool gelu = p.relu == ACT_GELU;
-  float sc4[4], bi4[4];                // this lane's 4 output columns (its wave takes part in exactly one pass)
+  const bool vec = (grow & 15) == 0 && (p.N & 7) == 0;   // whole, 16-byte aligned column groups in every row
+  float sc4[4], bi4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int n = n0 + (wc >> 1) * EPW + (wc & 1) * 64 + j * 16 + frow;
+    const int n = n0 + wc * 64 + j * 16 + frow;
     sc4[j] = (p.scale && n < p.N) ? p.scale[n] : 1.f;
     bi4[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
   }
+  __syncthreads();                     // every wave is done reading the ring
+  char* wst = smem + wave * (16 * SPW);
 #pragma unroll
-  for (int pass = 0; pass < C::BN / EPW; ++pass) {
-    __syncthreads();  // ring (or previous pass) fully consumed
-    if ((wc >> 1) == pass) {
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int lc = (wc & 1) * 64 + j * 16 + frow;
-        const float sc = sc4[j], bi = bi4[j];
+    for (int j = 0; j < 4; ++j) {
+      const int lc = j * 16 + frow;
+      float v[4];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          float v[4];
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[i][j][r] * sc4[j] + bi4[j], lo);
+      if (POOL == POOL_2x2) {
+        lds_put<float>(wst, SPW, fg, lc, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+      } else if (POOL == POOL_2x1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[i][j][r] * sc + bi, lo);
-          const int lr4 = wr * (MT * 16) + i * 16 + fg * 4;  // first of this lane's 4 consecutive tile rows
-          if (POOL == POOL_2x2) {
-            lds_put<float>(smem, SP, lr4 >> 2, lc, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-          } else if (POOL == POOL_2x1) {
+        for (int h = 0; h < 2; ++h) lds_put<float>(wst, SPW, fg * 2 + h, lc, fmaxf(v[2 * h], v[2 * h + 1]));
+      } else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) lds_put<float>(smem, SP, (lr4 >> 1) + h, lc, fmaxf(v[2 * h], v[2 * h + 1]));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lds_put<float>(smem, SP, lr4 + r, lc, v[r]);
-          }
-        }
+        for (int r = 0; r < 4; ++r) lds_put<float>(wst, SPW, fg * 4 + r, lc, v[r]);
       }
     }
-    __syncthreads();
-    const int nbase = n0 + pass * EPW;
-    if ((grow & 15) == 0 && oe == 4) {          // fp32 out: 4 columns per thread
-      constexpr int cpr = EPW / 4;
-      for (int c = tid; c < RQ * cpr; c += NTHREADS) {
-        const int row = c / cpr, ch = c - row * cpr;
-        const int q = q0 + row, n = nbase + ch * 4;
-        if (q < Mq && n < p.N) {
-          float4v a = *(const float4v*)(smem + row * SP + ch * 16);
-          if (gelu)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int qbase = (m0 + wr * (MT * 16) + i * 16) / PF;
+    if (vec && oe == 2) {
+      // f16 out: 8 columns per lane = one 16-byte store; 8 lanes cover a row's 64 columns (128 contiguous bytes)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = gelu_erf(a[k]);
-          if (p.res) {   // out = act(conv + residual): residual read with the same 16-byte coalescing as the store
-            const float4v r4 = *(const float4v*)(p.res + (size_t)q * grow + (size_t)n * 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const float t = a[k] + r4[k]; a[k] = p.relu == ACT_RELU ? fmaxf(t, 0.f) : t; }
-          }
-          *(float4v*)(p.out + (size_t)q * grow + (size_t)n * 4) = a;
-        }
-      }
-    } else if ((grow & 15) == 0) {               // f16 out: 8 columns per thread, one 16-byte store
-      constexpr int cpr = EPW / 8;
-      for (int c = tid; c < RQ * cpr; c += NTHREADS) {
-        const int row = c / cpr, ch = c - row * cpr;
-        const int q = q0 + row, n = nbase + ch * 8;
-        if (q < Mq && n < p.N) {
-          const float4v a0 = *(const float4v*)(smem + row * SP + ch * 32), a1 = *(const float4v*)(smem + row * SP + ch * 32 + 16);
+      for (int t = 0; t < (RT * 8 + 63) / 64; ++t) {
+        const int cidx = t * 64 + lane;
+        const int row = cidx >> 3, ch = cidx & 7;
+        const int q = qbase + row, n = n0 + wc * 64 + ch * 8;
+        if (row < RT && q < Mq && n < p.N) {
+          const float4v a0 = *(const float4v*)(wst + row * SPW + ch * 32), a1 = *(const float4v*)(wst + row * SPW + ch * 32 + 16);
           float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
           if (gelu)
 #pragma unroll
             for (int k = 0; k < 8; ++k) f[k] = gelu_erf(f[k]);
+          const size_t off = (size_t)q * grow + (size_t)n * 2;
           if (p.res) {
-            const half8 r8 = *(const half8*)(p.res + (size_t)q * grow + (size_t)n * 2);
+            const half8 r8 = *(const half8*)(p.res + off);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const float t = f[k] + (float)r8[k]; f[k] = p.relu == ACT_RELU ? fmaxf(t, 0.f) : t; }
+            for (int k = 0; k < 8; ++k) f[k] += (float)r8[k];
           }
           half8 o;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) o[k] = (_Float16)f[k];
-          *(half8*)(p.out + (size_t)q * grow + (size_t)n * 2) = o;
+          for (int k = 0; k < 8; ++k) o[k] = (_Float16)fmaxf(f[k], lo2);
+          *(half8*)(p.out + off) = o;
         }
       }
-    } else {  // ragged N (e.g. the 95-class prediction layer): element-wise
-      for (int e = tid; e < RQ * EPW; e += NTHREADS) {
-        const int row = e / EPW, col = e - row * EPW;
-        const int q = q0 + row, n = nbase + col;
-        if (q < Mq && n < p.N) {
-          float v = *(const float*)(smem + row * SP + col * 4);
-          if (gelu) v = gelu_erf(v);
-          if (oe == 4) *(float*)(p.out + (size_t)q * grow + (size_t)n * 4) = v;
-          else *(T*)(p.out + (size_t)q * grow + (size_t)n * sizeof(T)) = (T)v;
+    } else {
+#pragma unroll
+    for (int t = 0; t < RT * 16 / 64; ++t) {
+      const int cidx = t * 64 + lane;
+      const int row = cidx >> 4, ch = cidx & 15;
+      const int q = qbase + row, n = n0 + wc * 64 + ch * 4;
+      float4v a = *(const float4v*)(wst + row * SPW + ch * 16);
+      if (q < Mq && n < p.N) {
+        if (gelu)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a[k] = gelu_erf(a[k]);
+        const size_t off = (size_t)q * grow + (size_t)n * oe;
+        if (vec) {
+          if (p.res) a += *(const float4v*)(p.res + off);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a[k] = fmaxf(a[k], lo2);
+          *(float4v*)(p.out + off) = a;
+        } else {   // ragged N (e.g. the 95-class prediction layer): element-wise
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (n + k < p.N) {
+              float tv = a[k];
+              if (p.res) tv += oe == 4 ? *(const float*)(p.res + off + k * 4) : (float)*(const T*)(p.res + off + k * sizeof(T));
+              tv = fmaxf(tv, lo2);
+              if (oe == 4) *(float*)(p.out + off + k * 4) = tv;
+              else *(T*)(p.out + off + k * sizeof(T)) = (T)tv;
+            }
         }
       }
     }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
