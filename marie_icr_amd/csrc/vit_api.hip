@@ -74,7 +74,7 @@ extern "C" int mhip_vit_destroy(mhip_vit* m) {
   if (!m) return MHIP_OK;
   (void)hipStreamSynchronize(m->ctx->stream);
   m->arena.release();
-  if (m->pos_dev) (void)hipFree(m->pos_dev);
+  for (auto& t : m->pos_tables) (void)hipFree(t.dev);
   delete m;
   return MHIP_OK;
 }
@@ -235,7 +235,8 @@ extern "C" int mhip_vit_finalize(mhip_vit* m) {
   if (rc) return rc;
   m->ready = true;
   m->store.t.clear();
-  m->pos_hp = m->pos_wp = 0;
+  for (auto& t : m->pos_tables) (void)hipFree(t.dev);
+  m->pos_tables.clear();
   return MHIP_OK;
 }
 
@@ -275,14 +276,15 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
   vit_geometry(m, H32, W32, &g);
   run->g = g;
   const Arena& a = m->arena;
-  if (m->pos_hp != g.hp || m->pos_wp != g.wp) {   // resized position table, rebuilt only when the page geometry changes
-    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (m->pos_dev) (void)hipFree(m->pos_dev);
-    m->pos_dev = nullptr;
-    MHIP_HIP(ctx, hipMalloc((void**)&m->pos_dev, (size_t)g.np * D * 4));
-    int rc = mhip_launch_posemb_bicubic(ctx, a.d<float>("pos"), c.pos_h, c.pos_w, m->pos_dev, g.hp, g.wp, D);
+  float* pos_dev = nullptr;
+  for (const auto& t : m->pos_tables)
+    if (t.hp == g.hp && t.wp == g.wp) pos_dev = t.dev;
+  if (!pos_dev) {   // first page of this geometry: resize the position table once and keep it
+    if (m->pos_tables.size() >= 64) return mhip_fail(ctx, MHIP_ENOMEM, "vit: more than 64 distinct page geometries");
+    MHIP_HIP(ctx, hipMalloc((void**)&pos_dev, (size_t)g.np * D * 4));
+    m->pos_tables.push_back({g.hp, g.wp, pos_dev});
+    int rc = mhip_launch_posemb_bicubic(ctx, a.d<float>("pos"), c.pos_h, c.pos_w, pos_dev, g.hp, g.wp, D);
     if (rc) return rc;
-    m->pos_hp = g.hp; m->pos_wp = g.wp;
   }
   const size_t R = (size_t)B * g.npad;
   float* x = ws.take<float>(R * D * 4);
@@ -301,7 +303,7 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
   for (int b = 0; b < B; ++b) {
     char* A = hid + (size_t)b * g.np * K0 * es;
     if ((rc = mhip_launch_patchify(ctx, prec, imgs + (size_t)b * th * tw * 3, th, tw, g.hp, g.wp, P, swap_rb, 127.5f, 127.5f, A, K0))) return rc;
-    if ((rc = gemm(ctx, prec, A, a.d("pe_w"), g.np, D, K0, nullptr, a.d<float>("pe_b"), x + ((size_t)b * g.npad + 1) * D, ACT_NONE, 1, m->pos_dev))) return rc;
+    if ((rc = gemm(ctx, prec, A, a.d("pe_w"), g.np, D, K0, nullptr, a.d<float>("pe_b"), x + ((size_t)b * g.npad + 1) * D, ACT_NONE, 1, pos_dev))) return rc;
   }
   if ((rc = mhip_launch_token_init(ctx, x, a.d<float>("cls"), B, g.npad, g.n_tok, D))) return rc;
   int tap_at = 0;

@@ -8,8 +8,10 @@ struct mhip_vit {
   mhip_vit_config cfg{};
   TensorStore store;
   Arena arena;
-  float* pos_dev = nullptr;   // position table resized to the current patch grid
-  int pos_hp = 0, pos_wp = 0;
+  // position tables resized to the patch grids seen so far (mixed-DPI streams alternate between a few page sizes);
+  // built once per geometry, never inside a steady-state forward
+  struct PosTable { int hp, wp; float* dev; };
+  std::vector<PosTable> pos_tables;
   bool ready = false;
   size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
 };

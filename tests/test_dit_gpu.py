@@ -216,3 +216,22 @@ def test_box_processor_vs_oracle_pipeline(ctx, small_case):
     # RAW_LINE / WORD: the whole image is the single fragment
     r2 = bp.extract_bounding_boxes("t", "k", page, PSMode.RAW_LINE)
     assert r2[0] == [[0, 0, page.shape[1], page.shape[0]]] and r2[2] == [0]
+
+
+def test_mixed_page_sizes_interleaved(ctx, small_case):
+    """BASELINE configs[4] (mixed-DPI stream): pages of different sizes alternate; a page's boxes do not depend on what
+    ran before it (position tables and workspaces are per geometry)."""
+    from marie_icr_amd._lib import PREC_F16
+    from marie_icr_amd.dit import DitModel
+    from marie_icr_amd.weights import make_image_u8
+
+    st, page, *_ = small_case
+    m = DitModel(ctx, st, precision=PREC_F16, config=_config(ctx))
+    other = [make_image_u8(40 + i, 1, h, w)[0] for i, (h, w) in enumerate(((248, 192), (412, 318)))]
+    first = m.detect_host(page)[0]
+    for o in other:
+        assert len(m.detect_host(o)[0][0]) > 0
+    again = m.detect_host(page)[0]
+    np.testing.assert_array_equal(first[0], again[0])
+    np.testing.assert_array_equal(first[1], again[1])
+    m.close()
