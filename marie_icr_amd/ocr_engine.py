@@ -13,6 +13,7 @@ marie/utils/image_utils.py:190-252) is not provided on this path and raises if r
 from __future__ import annotations
 
 import hashlib
+from copy import deepcopy
 from enum import Enum
 from itertools import chain
 from math import ceil
@@ -206,3 +207,149 @@ class MarieHipOcrEngine(OcrEngine):
                 **kwargs: Any) -> List[Dict]:
         return self.process_single(self.box_processor, self.ocr_processor, frames, pms_mode, coordinate_format,
                                    regions, queue_id, **kwargs)
+
+
+class _MemoBoxProcessor:
+    """One detection per (frame, mode) inside a single ``extract`` call: every recognizer of the vote sees the same boxes
+    and fragments (the reference re-runs its detector per recognizer on full pages and gets the same answer)."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self._memo: Dict[Any, Any] = {}
+
+    def extract_bounding_boxes(self, _id, key, img, psm=PSMode.SPARSE, **kwargs):
+        k = (id(img), psm, tuple(sorted(kwargs.items())))
+        if k not in self._memo:
+            self._memo[k] = (img, self.inner.extract_bounding_boxes(_id, key, img, psm, **kwargs))   # keeps img alive: id stays unique
+        return self._memo[k][1]
+
+
+def vote_words(candidates: List[Dict], min_vote_count: int = 2, by_confidence: Optional[Dict] = None) -> Dict:
+    """Pick one word among the recognizers' candidates for the same box (all carry the same ``id``).
+    reference: VotingOcrEngine.get_words_by_vote_by_selector / voting_evaluator, marie/ocr/voting_ocr_engine.py:186-254,
+    420-466: the largest group of identical texts wins if it has at least ``min_vote_count`` members (equal sizes: larger
+    confidence sum; the first such group keeps ties); otherwise the default recognizer's word (the first candidate), unless
+    the per-id best-confidence word beats it."""
+    groups: Dict[str, List[Dict]] = {}
+    for w in candidates:
+        groups.setdefault(w["text"], []).append(w)
+    best: List[Dict] = []
+    for g in groups.values():
+        if len(g) > len(best) or (len(g) == len(best) and sum(w["confidence"] for w in g) > sum(w["confidence"] for w in best)):
+            best = g
+    if len(best) >= min_vote_count:
+        chosen = best[0]
+        votes = deepcopy(best)
+        for v in votes:
+            v.pop("box", None)
+            v.pop("strategy", None)
+        chosen["strategy"] = {"type": "voting", "candidates": len(best), "votes": votes}
+        return chosen
+    chosen = candidates[0]
+    chosen["strategy"] = {"type": "default"}
+    top = by_confidence if by_confidence is not None else max(candidates, key=lambda w: w["confidence"])
+    if top is not None and top["confidence"] > chosen["confidence"]:
+        chosen = top
+        chosen["strategy"] = {"type": "confidence", "confidence": top["confidence"]}
+    return chosen
+
+
+def voting_evaluator(aggregated_results: "OrderedDict[str, Any]", default_results, regions=None):
+    """reference: VotingOcrEngine.voting_evaluator, marie/ocr/voting_ocr_engine.py:256-482.  Debug JSON dumps and prints
+    are dropped.  Region mode: the reference looks results up by ``extended[i]["id"]``, a key its own engine never sets
+    (ocr_engine.py:370); here an entry without ``id`` is addressed by its position."""
+    has_regions = regions is not None and len(regions) > 0
+    if has_regions and len(aggregated_results) == 0:
+        out = {} if default_results is None else deepcopy(default_results)
+        out["regions"] = []
+        for region in regions:
+            region.update({"confidence": 0, "text": "", "original_text": "", "words": []})
+            out["regions"].append(region)
+        return out
+    by_unit: Dict[Any, Dict[str, List[Dict]]] = {}
+    for name, res in aggregated_results.items():
+        units = res["extended"] if has_regions else res
+        for idx, unit in enumerate(units):
+            uid = unit.get("id", idx) if has_regions else idx
+            slot = by_unit.setdefault(uid, {})
+            for word in unit.get("words", []):
+                word["id"] = str(word["id"]) if not has_regions else word["id"]
+                word["processor"] = name
+                slot.setdefault(word["id"], []).append(word)
+    voted: Dict[Any, List[Dict]] = {}
+    for uid, words_by_id in by_unit.items():
+        voted[uid] = []
+        for wid, cands in words_by_id.items():
+            top = cands[0]
+            for c in cands:                     # first strictly-larger confidence wins, as in the reference's scan
+                if c["confidence"] > top["confidence"]:
+                    top = c
+            voted[uid].append(vote_words(cands, 2, top))
+    out = deepcopy(default_results)
+    if not has_regions:
+        for idx, page in enumerate(out):
+            page["words"] = voted[idx]
+        return out
+    for idx, ext in enumerate(out["extended"]):
+        uid = ext.get("id", idx)
+        if uid in voted:
+            ext["words"] = voted[uid]
+    for region in out["regions"]:
+        rid = region["id"] = str(region["id"])
+        for idx, ext in enumerate(out["extended"]):
+            if str(ext.get("id", "")) == rid:
+                ext["words"].sort(key=lambda w: w["word_index"])
+                conf = sum(w["confidence"] for w in ext["words"]) / len(ext["words"]) if ext["words"] else 0
+                region["original_text"] = region["text"]
+                region["text"] = " ".join(w["text"] for w in ext["words"])
+                region["confidence"] = round(conf, 4)
+    return out
+
+
+class MarieHipVotingOcrEngine(OcrEngine):
+    """Counterpart of ``VotingOcrEngine`` (marie/ocr/voting_ocr_engine.py:22-482): every enabled recognizer reads the same
+    boxes, then the words are voted on.  ``processors``: ordered mapping name -> recognizer; the first one is the default
+    (the reference wires TrOcrProcessor as "default" and CraftOcrProcessor as "craft")."""
+
+    def __init__(self, models_dir: Optional[str] = None, cuda: bool = True, *, box_processor=None,
+                 default_ocr_processor=None, processors=None, **kwargs) -> None:
+        super().__init__(models_dir=models_dir, cuda=cuda, box_processor=box_processor, **kwargs)
+        from collections import OrderedDict
+
+        self.processors = OrderedDict()
+        if default_ocr_processor is not None:
+            self.processors["default"] = {"enabled": True, "default": True, "processor": default_ocr_processor}
+        for name, proc in (processors or {}).items():
+            self.processors[name] = proc if isinstance(proc, dict) else {"enabled": True, "processor": proc}
+        if not self.processors:
+            raise ValueError("pass the MI355X recognizers explicitly (default_ocr_processor=..., processors={...})")
+        first = next(iter(self.processors.values()))
+        first.setdefault("default", True)
+
+    def extract(self, frames, pms_mode: PSMode = PSMode.SPARSE,
+                coordinate_format: CoordinateFormat = CoordinateFormat.XYXY, regions=None, queue_id: str = None,
+                **kwargs: Any):
+        from collections import OrderedDict
+
+        global bbox_cache
+        ro_frames = OcrEngine.as_frames(frames)
+        memo = _MemoBoxProcessor(self.box_processor)
+        aggregated, default_results, is_default = OrderedDict(), None, False
+        for name, val in self.processors.items():
+            if not val.get("enabled", True):
+                continue
+            is_default = is_default or bool(val.get("default"))
+            try:
+                results = self.process_single(memo, val["processor"], ro_frames, pms_mode, coordinate_format, regions,
+                                              queue_id, **kwargs)
+            except Exception:                    # a failing recognizer drops out of the vote, as in the reference
+                import traceback
+
+                traceback.print_exc()
+                continue
+            finally:
+                bbox_cache = {}
+            aggregated[name] = results
+            if is_default:                      # the reference's flag stays set once the default recognizer was seen
+                default_results = results
+        return voting_evaluator(aggregated, default_results, regions)

@@ -140,3 +140,33 @@ def test_engine_with_dit_detector_and_trocr_recognizer(ctx):
     assert all(0.0 <= w["confidence"] <= 1.0 for w in words)
     assert {w["line"] for w in words} == {ln["line"] for ln in lines}
     assert len(line_boxes) >= 1
+
+
+def test_voting_engine_two_recognizers_one_detection(ctx):
+    """MarieHipVotingOcrEngine: CRAFT boxes once, CRNN (CTC) and the production ICR (Attn) recognizers both read them,
+    words are voted per box."""
+    from marie_icr_amd.box_processor import PSMode
+    from marie_icr_amd.craft import BoxProcessorCraft
+    from marie_icr_amd.crnn import CrnnOcrProcessor
+    from marie_icr_amd.icr import CraftOcrProcessor
+    from marie_icr_amd.ocr_engine import CoordinateFormat, MarieHipVotingOcrEngine
+    from marie_icr_amd.weights import make_craft_state, make_crnn_state, make_icr_state, make_page_bgr
+
+    calls = []
+    box = BoxProcessorCraft(state=make_craft_state(5), precision="f32", ctx=ctx)
+    inner = box.extract_bounding_boxes
+    box.extract_bounding_boxes = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    a = CrnnOcrProcessor(state=make_crnn_state(0), precision="f32", img_w=128, ctx=ctx)
+    b = CraftOcrProcessor(state=make_icr_state(0), precision="f32", ctx=ctx)
+    eng = MarieHipVotingOcrEngine(box_processor=box, default_ocr_processor=a, processors={"craft": b})
+    page = make_page_bgr(5, 300, 240)
+    res = eng.extract([page], PSMode.SPARSE, CoordinateFormat.XYWH)
+    assert len(calls) == 1, "the detector must run once for both recognizers"
+    words = res[0]["words"]
+    assert len(words) == 5
+    ra = {str(w["id"]): w for w in MarieHipVotingOcrEngine(box_processor=box, default_ocr_processor=a).extract([page], PSMode.SPARSE, CoordinateFormat.XYWH)[0]["words"]}
+    for w in words:
+        assert w["strategy"]["type"] in ("voting", "default", "confidence")
+        assert w["processor"] in ("default", "craft")
+        if w["strategy"]["type"] == "default":
+            assert w["text"] == ra[w["id"]]["text"]
