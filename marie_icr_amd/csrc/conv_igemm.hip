@@ -29,6 +29,10 @@
 //     XCD's L2, and vertically adjacent m-tiles share their halo rows.
 //   * f16 operands use v_mfma_f32_16x16x32_f16; the exact-fp32 parity mode uses
 //     v_mfma_f32_16x16x4_f32 on the same LDS image (k order permuted identically for A and W).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "igemm_common.h"
 
 using namespace igemm;
@@ -296,85 +300,103 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   }
   __syncthreads();                     // every wave is done reading the ring
   char* wst = smem + wave * (16 * SPW);
+  // One specialised copy of the row-tile loop per (output type, residual, GELU) combination, chosen once: the loop is
+  // unrolled over the 8 row-tiles (accumulators are registers), so every uniform test left inside it is replicated and
+  // the kernel's code outgrows the instruction cache two CUs share — which slows the neighbour's main loop as well.
+  auto body = [&](auto OUT32_, auto RES_, auto GELU_, auto VEC_) {
+    constexpr bool OUT32 = decltype(OUT32_)::value, RES = decltype(RES_)::value, GELU = decltype(GELU_)::value,
+                   VEC = decltype(VEC_)::value;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int lc = j * 16 + frow;
-      float v[4];
+      for (int j = 0; j < 4; ++j) {
+        const int lc = j * 16 + frow;
+        float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[i][j][r] * sc4[j] + bi4[j], lo);
-      if (POOL == POOL_2x2) {
-        lds_put<float>(wst, SPW, fg, lc, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-      } else if (POOL == POOL_2x1) {
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[i][j][r] * sc4[j] + bi4[j], lo);
+        if (POOL == POOL_2x2) {
+          lds_put<float>(wst, SPW, fg, lc, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        } else if (POOL == POOL_2x1) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) lds_put<float>(wst, SPW, fg * 2 + h, lc, fmaxf(v[2 * h], v[2 * h + 1]));
+          for (int h = 0; h < 2; ++h) lds_put<float>(wst, SPW, fg * 2 + h, lc, fmaxf(v[2 * h], v[2 * h + 1]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds_put<float>(wst, SPW, fg * 4 + r, lc, v[r]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int qbase = (m0 + wr * (MT * 16) + i * 16) / PF;
+      if (VEC && !OUT32) {
+        // f16 out: 8 columns per lane = one 16-byte store; 8 lanes cover a row's 64 columns (128 contiguous bytes)
+#pragma unroll
+        for (int t = 0; t < (RT * 8 + 63) / 64; ++t) {
+          const int cidx = t * 64 + lane;
+          const int row = cidx >> 3, ch = cidx & 7;
+          const int q = qbase + row, n = n0 + wc * 64 + ch * 8;
+          if (row < RT && q < Mq && n < p.N) {
+            const float4v a0 = *(const float4v*)(wst + row * SPW + ch * 32), a1 = *(const float4v*)(wst + row * SPW + ch * 32 + 16);
+            float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            if (GELU)
+#pragma unroll
+              for (int k = 0; k < 8; ++k) f[k] = gelu_erf(f[k]);
+            const size_t off = (size_t)q * grow + (size_t)n * 2;
+            if (RES) {
+              const half8 r8 = *(const half8*)(p.res + off);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] + (float)r8[k], lo2);
+            }
+            half8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (_Float16)f[k];
+            *(half8*)(p.out + off) = o;
+          }
+        }
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lds_put<float>(wst, SPW, fg * 4 + r, lc, v[r]);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int qbase = (m0 + wr * (MT * 16) + i * 16) / PF;
-    if (vec && oe == 2) {
-      // f16 out: 8 columns per lane = one 16-byte store; 8 lanes cover a row's 64 columns (128 contiguous bytes)
+        for (int t = 0; t < RT * 16 / 64; ++t) {
+          const int cidx = t * 64 + lane;
+          const int row = cidx >> 4, ch = cidx & 15;
+          const int q = qbase + row, n = n0 + wc * 64 + ch * 4;
+          float4v a = *(const float4v*)(wst + row * SPW + ch * 16);
+          if (q < Mq && n < p.N) {
+            if (GELU)
 #pragma unroll
-      for (int t = 0; t < (RT * 8 + 63) / 64; ++t) {
-        const int cidx = t * 64 + lane;
-        const int row = cidx >> 3, ch = cidx & 7;
-        const int q = qbase + row, n = n0 + wc * 64 + ch * 8;
-        if (row < RT && q < Mq && n < p.N) {
-          const float4v a0 = *(const float4v*)(wst + row * SPW + ch * 32), a1 = *(const float4v*)(wst + row * SPW + ch * 32 + 16);
-          float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-          if (gelu)
+              for (int k = 0; k < 4; ++k) a[k] = gelu_erf(a[k]);
+            const size_t off = (size_t)q * grow + (size_t)n * oe;
+            if (VEC) {     // fp32 out
+              if (RES) {
+                a += *(const float4v*)(p.res + off);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] = gelu_erf(f[k]);
-          const size_t off = (size_t)q * grow + (size_t)n * 2;
-          if (p.res) {
-            const half8 r8 = *(const half8*)(p.res + off);
+                for (int k = 0; k < 4; ++k) a[k] = fmaxf(a[k], lo2);
+              }
+              *(float4v*)(p.out + off) = a;
+            } else {       // ragged N (e.g. the 95-class prediction layer): element-wise, everything decided at run time
 #pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] += (float)r8[k];
-          }
-          half8 o;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) o[k] = (_Float16)fmaxf(f[k], lo2);
-          *(half8*)(p.out + off) = o;
-        }
-      }
-    } else {
-#pragma unroll
-    for (int t = 0; t < RT * 16 / 64; ++t) {
-      const int cidx = t * 64 + lane;
-      const int row = cidx >> 4, ch = cidx & 15;
-      const int q = qbase + row, n = n0 + wc * 64 + ch * 4;
-      float4v a = *(const float4v*)(wst + row * SPW + ch * 16);
-      if (q < Mq && n < p.N) {
-        if (gelu)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) a[k] = gelu_erf(a[k]);
-        const size_t off = (size_t)q * grow + (size_t)n * oe;
-        if (vec) {
-          if (p.res) a += *(const float4v*)(p.res + off);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) a[k] = fmaxf(a[k], lo2);
-          *(float4v*)(p.out + off) = a;
-        } else {   // ragged N (e.g. the 95-class prediction layer): element-wise
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (n + k < p.N) {
-              float tv = a[k];
-              if (p.res) tv += oe == 4 ? *(const float*)(p.res + off + k * 4) : (float)*(const T*)(p.res + off + k * sizeof(T));
-              tv = fmaxf(tv, lo2);
-              if (oe == 4) *(float*)(p.out + off + k * 4) = tv;
-              else *(T*)(p.out + off + k * sizeof(T)) = (T)tv;
+              for (int k = 0; k < 4; ++k)
+                if (n + k < p.N) {
+                  float tv = a[k];
+                  if (p.res) tv = fmaxf(tv + (oe == 4 ? *(const float*)(p.res + off + k * 4) : (float)*(const T*)(p.res + off + k * sizeof(T))), lo2);
+                  if (oe == 4) *(float*)(p.out + off + k * 4) = tv;
+                  else *(T*)(p.out + off + k * sizeof(T)) = (T)tv;
+                }
             }
+          }
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+  };
+  typedef std::true_type Y;
+  typedef std::false_type N_;
+  const bool has_res = p.res != nullptr;
+  if (!vec) {
+    if (gelu) body(N_{}, N_{}, Y{}, N_{}); else body(N_{}, N_{}, N_{}, N_{});
+  } else if (oe == 4) {
+    if (gelu) body(Y{}, N_{}, Y{}, Y{}); else if (has_res) body(Y{}, Y{}, N_{}, Y{}); else body(Y{}, N_{}, N_{}, Y{});
+  } else {
+    if (gelu) body(N_{}, N_{}, Y{}, Y{}); else if (has_res) body(N_{}, Y{}, N_{}, Y{}); else body(N_{}, N_{}, N_{}, Y{});
   }
 }
 
@@ -503,7 +525,8 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
     const int r = mhip_try_launch_conv3x3_patch(ctx, precision, d, a);   // 3x3 / pad 1 / dense: patch kernel
     if (r <= 0) return r;
   }
-  const int bn = (a.N > 128) ? 256 : (a.N > 64 ? 128 : 64);
+  static const int force_bn = getenv("MARIE_HIP_FORCE_BN") ? atoi(getenv("MARIE_HIP_FORCE_BN")) : 0;   // tuning aid
+  const int bn = force_bn ? force_bn : ((a.N > 128) ? 256 : (a.N > 64 ? 128 : 64));
   const int bm = (bn == 64) ? 512 : 256;
   a.mtiles = (a.M + bm - 1) / bm;
   a.ntiles = (a.N + bn - 1) / bn;
