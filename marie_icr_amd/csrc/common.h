@@ -262,7 +262,8 @@ struct DecAttnDesc {
 };
 int mhip_launch_decode_attention(mhip_ctx* ctx, int precision, const DecAttnDesc& d);
 struct BeamCandDesc {
-  const float* logits = nullptr;   // [bsz*beam][ld]
+  const void* logits = nullptr;    // [bsz*beam][ld], fp32 or f16
+  int logits_f16 = 0;
   int ld = 0, vocab = 0, beam = 1, bsz = 0;
   const float* cum = nullptr;      // [bsz*beam]
   int step = 0, max_len = 0, min_len = 1, pad = 1, eos = 2;

@@ -207,12 +207,12 @@ static size_t trocr_ws_bytes(const mhip_trocr* m, int n) {
   const size_t es = m->esz(), D = c.dec_dim, M = (size_t)n * c.beam, ML = trocr_max_len(c);
   VitGeom vg;
   vit_geometry(m->vit, c.img_size, c.img_size, &vg);
-  const size_t ldv = (c.vocab + 3) / 4 * 4;
+  const size_t ldv = (c.vocab + 7) / 8 * 8;
   size_t b = vit_workspace_bytes(m->vit, n, vg);
   b += 2 * (size_t)c.dec_layers * n * vg.npad * D * es;               // cross K / V
   b += 2 * (size_t)c.dec_layers * (ML + 1) * M * D * es;              // self K / V history
   b += M * D * 4 + 3 * M * D * es + M * c.dec_ffn * es + M * ldv * 4; // x, xt, q, ao, hidden, logits
-  b += 2 * M * (ML + 2) * 4 + 4 * M * 4 + (size_t)n * 2 * c.beam * 12 + (size_t)vg.n_tok * c.enc_dim * 4;
+  b += 2 * M * (ML + 2) * 4 + 4 * M * 4 + (size_t)n * 2 * c.beam * 12 + (size_t)vg.n_tok * c.enc_dim * 4 + (size_t)c.vocab * 4 + 4096;
   return b + (1 << 16);
 }
 
@@ -230,7 +230,7 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
   const int prec = m->precision, D = c.dec_dim, E = c.enc_dim, F = c.dec_ffn, beam = c.beam, L = c.dec_layers;
   const int K2 = 2 * beam, ML = trocr_max_len(c), M = n * beam;
   const size_t es = m->esz();
-  const int ldv = (c.vocab + 3) / 4 * 4;
+  const int ldv = (c.vocab + 7) / 8 * 8;
   int rc = mhip_ensure_workspace(ctx, trocr_ws_bytes(m, n));
   if (rc) return rc;
   Carver ws(ctx->ws);
@@ -264,7 +264,7 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
   char* qb = ws.take((size_t)M * D * es);
   char* ao = ws.take((size_t)M * D * es);
   char* hid = ws.take((size_t)M * F * es);
-  float* logits = ws.take<float>((size_t)M * ldv * 4);
+  char* logits = ws.take((size_t)M * ldv * 4);      // element type T: f16 logits in the f16 mode, fp32 in the parity mode
   const int anc_ld = ML + 2;
   int* anc[2] = {ws.take<int>((size_t)M * anc_ld * 4), ws.take<int>((size_t)M * anc_ld * 4)};
   int* d_tok = ws.take<int>((size_t)M * 4);
@@ -329,13 +329,17 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
       if ((rc = mhip_gemm(ctx, prec, hid, a.d(lay(l, "fc2_w")), M, D, F, nullptr, a.d<float>(lay(l, "fc2_b")), x, ACT_NONE, 1, x))) return rc;
       if ((rc = mhip_launch_layernorm2(ctx, prec, x, a.d<float>(lay(l, "fin_ln") + "_g"), a.d<float>(lay(l, "fin_ln") + "_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
     }
-    if ((rc = mhip_gemm(ctx, prec, xt, a.d("out_w"), M, c.vocab, D, nullptr, nullptr, logits, ACT_NONE, 1, nullptr, ldv))) return rc;
+    if ((rc = mhip_gemm(ctx, prec, xt, a.d("out_w"), M, c.vocab, D, nullptr, nullptr, logits, ACT_NONE, 0, nullptr, ldv))) return rc;
     if (step == 0 && step0_logits_host) {
-      for (int i = 0; i < n; ++i)
-        MHIP_HIP(ctx, hipMemcpyAsync(step0_logits_host + (size_t)i * c.vocab, logits + (size_t)i * beam * ldv, (size_t)c.vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+      float* stage = ws.take<float>((size_t)c.vocab * 4);
+      for (int i = 0; i < n; ++i) {
+        if ((rc = mhip_launch_convert_rows(ctx, prec, logits + (size_t)i * beam * ldv * es, stage, 1, c.vocab))) return rc;
+        MHIP_HIP(ctx, hipMemcpyAsync(step0_logits_host + (size_t)i * c.vocab, stage, (size_t)c.vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      }
     }
     BeamCandDesc bc;
-    bc.logits = logits; bc.ld = ldv; bc.vocab = c.vocab; bc.beam = beam; bc.bsz = n; bc.cum = d_cum; bc.step = step;
+    bc.logits = logits; bc.logits_f16 = prec == MHIP_PREC_F16; bc.ld = ldv; bc.vocab = c.vocab; bc.beam = beam; bc.bsz = n; bc.cum = d_cum; bc.step = step;
     bc.max_len = ML; bc.min_len = c.min_len; bc.pad = c.pad; bc.eos = c.eos;
     bc.cand_scores = d_cs; bc.cand_tokens = d_ct; bc.cand_beams = d_cb;
     if ((rc = mhip_launch_beam_candidates(ctx, bc))) return rc;

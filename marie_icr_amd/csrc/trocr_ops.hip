@@ -108,11 +108,11 @@ struct DecAttnArgs {
   int n_keys, nq;
 };
 
-constexpr int DA_MAXK = 640, DA_MAXQ = 4, DA_WAVES = 4;
+constexpr int DA_WAVES = 4;   // (MAXQ, MAXK) instantiations: cross-attention (4, 640), self-attention (1, 256)
 
 // One WAVE per (group, head): a 16-byte chunk of a key row per lane, so a wave-instruction reads whole 128-byte (f16) /
 // 256-byte (fp32) head rows of 8 / 4 consecutive keys — every K and V byte is fetched once, fully coalesced.
-template <typename T>
+template <typename T, int DA_MAXQ, int DA_MAXK>
 __global__ __launch_bounds__(64 * DA_WAVES) void decode_attn_kernel(DecAttnArgs p, int heads, int tasks) {
   constexpr int EPC = 16 / (int)sizeof(T);        // elements per chunk: 8 / 4
   constexpr int CPR = 64 / EPC;                   // chunks per head row: 8 / 16
@@ -193,7 +193,9 @@ __global__ __launch_bounds__(64 * DA_WAVES) void decode_attn_kernel(DecAttnArgs 
       }
     }
   __syncthreads();
-  float inv[DA_MAXQ] = {0.f, 0.f, 0.f, 0.f};
+  float inv[DA_MAXQ];
+#pragma unroll
+  for (int qi = 0; qi < DA_MAXQ; ++qi) inv[qi] = 0.f;
   if (live)
     for (int qi = 0; qi < p.nq; ++qi) {
       float m = -INFINITY;
@@ -256,7 +258,7 @@ __device__ __forceinline__ float okey_inv(unsigned k) {
 }
 
 struct CandArgs {
-  const float* logits;    // [bsz*beam][ld]
+  const void* logits;     // [bsz*beam][ld], fp32 or f16 (LT)
   int ld, vocab, beam;
   const float* cum;       // [bsz*beam] cumulative score of each hypothesis (scores[:, step-1]); unused at step 0
   int step, max_len, min_len;
@@ -268,33 +270,41 @@ struct CandArgs {
 
 constexpr int CAND_T = 1024, CAND_K = 8;   // per-thread shortlist length (>= 2 * beam)
 
-// one workgroup per crop
+// one workgroup per crop; LT = element type of the logits (the GEMM's output type)
+template <typename LT>
 __global__ __launch_bounds__(CAND_T) void beam_candidates_kernel(CandArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64* keys = (u64*)smem;                 // CAND_T * CAND_K
-  __shared__ float rmax[8], rlse[8];
-  __shared__ float wred[16];
+  __shared__ float rlse[8];
+  __shared__ float wred[16], wsum[16];
   const int sample = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nb = p.step == 0 ? 1 : p.beam;          // step 0: all beams are identical, only the first one competes
   const int K = 2 * p.beam;
-  // log-sum-exp per hypothesis row
+  // log-sum-exp per hypothesis row: ONE pass (running max + rescaled sum per thread, merged across the workgroup)
   for (int b = 0; b < nb; ++b) {
-    const float* row = p.logits + (size_t)(sample * p.beam + b) * p.ld;
-    float m = -INFINITY;
-    for (int i = tid; i < p.vocab; i += CAND_T) m = fmaxf(m, row[i]);
+    const LT* row = (const LT*)p.logits + (size_t)(sample * p.beam + b) * p.ld;
+    float m = -INFINITY, s = 0.f;
+    for (int i = tid; i < p.vocab; i += CAND_T) {
+      const float x = (float)row[i];
+      if (x > m) { s = s * expf(m - x) + 1.f; m = x; }
+      else s += expf(x - m);
+    }
 #pragma unroll
-    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) wred[wv] = m;
+    for (int o = 32; o; o >>= 1) {
+      const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+      const float mm = fmaxf(m, m2);
+      s = (m == -INFINITY ? 0.f : s * expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - mm));
+      m = mm;
+    }
+    if (lane == 0) { wred[wv] = m; wsum[wv] = s; }
     __syncthreads();
-    if (tid == 0) { float mm = wred[0]; for (int w = 1; w < 16; ++w) mm = fmaxf(mm, wred[w]); rmax[b] = mm; }
-    __syncthreads();
-    m = rmax[b];
-    float s = 0.f;
-    for (int i = tid; i < p.vocab; i += CAND_T) s += expf(row[i] - m);
-    s = wave_sum(s);
-    if (lane == 0) wred[wv] = s;
-    __syncthreads();
-    if (tid == 0) { float ss = 0.f; for (int w = 0; w < 16; ++w) ss += wred[w]; rlse[b] = m + logf(ss); }
+    if (tid == 0) {
+      float mm = wred[0];
+      for (int w = 1; w < 16; ++w) mm = fmaxf(mm, wred[w]);
+      float ss = 0.f;
+      for (int w = 0; w < 16; ++w) ss += wred[w] == -INFINITY ? 0.f : wsum[w] * expf(wred[w] - mm);
+      rlse[b] = mm + logf(ss);
+    }
     __syncthreads();
   }
   // per-thread shortlist of the K best (score, flat index) pairs; flat index = b * vocab + token
@@ -302,10 +312,10 @@ __global__ __launch_bounds__(CAND_T) void beam_candidates_kernel(CandArgs p) {
 #pragma unroll
   for (int j = 0; j < CAND_K; ++j) best[j] = 0;
   for (int b = 0; b < nb; ++b) {
-    const float* row = p.logits + (size_t)(sample * p.beam + b) * p.ld;
+    const LT* row = (const LT*)p.logits + (size_t)(sample * p.beam + b) * p.ld;
     const float base = (p.step == 0 ? 0.f : p.cum[sample * p.beam + b]);
     for (int i = tid; i < p.vocab; i += CAND_T) {
-      float lp = row[i] - rlse[b];
+      float lp = (float)row[i] - rlse[b];
       if (lp != lp) lp = -INFINITY;
       if (i == p.pad) lp = -INFINITY;
       if (p.step >= p.max_len && i != p.eos) lp = -INFINITY;
@@ -398,15 +408,18 @@ int mhip_launch_embed_step(mhip_ctx* ctx, int precision, const int* tokens, cons
 }
 
 int mhip_launch_decode_attention(mhip_ctx* ctx, int precision, const DecAttnDesc& d) {
-  if (d.n_keys < 1 || d.n_keys > DA_MAXK || d.nq < 1 || d.nq > DA_MAXQ || d.heads < 1 || d.groups < 1)
+  if (d.n_keys < 1 || d.n_keys > 640 || d.nq < 1 || d.nq > 4 || d.heads < 1 || d.groups < 1)
     return mhip_fail(ctx, MHIP_EINVAL, "decode_attention: n_keys %d nq %d", d.n_keys, d.nq);
+  const bool small = d.nq == 1 && d.n_keys <= 256;   // self-attention over a short history: 4 KB of LDS, full occupancy
   DecAttnArgs a;
   a.q = d.q; a.k = d.k; a.v = d.v; a.out = d.out; a.anc = d.anc; a.anc_ld = d.anc_ld; a.slots = d.slots;
   a.kv_rows = d.kv_rows; a.ldq = d.ldq; a.ldk = d.ldk; a.ldo = d.ldo; a.n_keys = d.n_keys; a.nq = d.nq;
   const int tasks = d.heads * d.groups;
   dim3 grid((tasks + DA_WAVES - 1) / DA_WAVES), block(64 * DA_WAVES);
-  if (precision == MHIP_PREC_F16) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(decode_attn_kernel<_Float16>, grid, block, 0, ctx->stream, a, d.heads, tasks));
-  else PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(decode_attn_kernel<float>, grid, block, 0, ctx->stream, a, d.heads, tasks));
+#define DA_LAUNCH(T, Q, K) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL((decode_attn_kernel<T, Q, K>), grid, block, 0, ctx->stream, a, d.heads, tasks))
+  if (precision == MHIP_PREC_F16) { if (small) DA_LAUNCH(_Float16, 1, 256); else DA_LAUNCH(_Float16, 4, 640); }
+  else { if (small) DA_LAUNCH(float, 1, 256); else DA_LAUNCH(float, 4, 640); }
+#undef DA_LAUNCH
   CHECK_LAUNCH(ctx, "decode_attention");
   return 0;
 }
@@ -418,12 +431,8 @@ int mhip_launch_beam_candidates(mhip_ctx* ctx, const BeamCandDesc& d) {
   a.max_len = d.max_len; a.min_len = d.min_len; a.pad = d.pad; a.eos = d.eos;
   a.cand_scores = d.cand_scores; a.cand_tokens = d.cand_tokens; a.cand_beams = d.cand_beams;
   const int lds = (1024 + 64) * 8;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)beam_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr = true;
-  }
-  PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(beam_candidates_kernel, dim3(d.bsz), dim3(CAND_T), lds, ctx->stream, a));
+  if (d.logits_f16) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(beam_candidates_kernel<_Float16>, dim3(d.bsz), dim3(CAND_T), lds, ctx->stream, a));
+  else PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(beam_candidates_kernel<float>, dim3(d.bsz), dim3(CAND_T), lds, ctx->stream, a));
   CHECK_LAUNCH(ctx, "beam_candidates");
   return 0;
 }
