@@ -79,3 +79,23 @@ def test_deit_variant_vs_oracle(ctx):
         got = m.forward_host(imgs, (384, 384), swap_rb=False, want_tokens=True, want_fpn=False)["tokens"]
         assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (prec, np.abs(got - ref).max())
         m.close()
+
+
+def test_large_width_vs_oracle(ctx):
+    """dim 1024 / 16 heads (dit_large_patch16, beit_large_patch16_384 widths) at reduced depth: the D = 1024 LayerNorm,
+    GEMM and attention shapes."""
+    from marie_icr_amd._lib import PREC_F16, PREC_F32
+    from marie_icr_amd.vit import VitModel, make_config
+    from oracle.vit_torch import TorchVitOracle
+
+    st = make_vit_state(3, 1024, 4, 16)
+    imgs = make_image_u8(4, 1, 100, 70)
+    o = TorchVitOracle(st, 16, taps=(0, 1, 2, 3))
+    _, ref = o.forward_features(o.preprocess(imgs, 128, 96, swap_rb=True))
+    for prec, tol in ((PREC_F32, 1e-3), (PREC_F16, 0.03)):
+        m = VitModel(ctx, make_config(1024, 4, 16, (0, 1, 2, 3)), st, prec)
+        out = m.forward_host(imgs, (128, 96))
+        for j, f in enumerate(out["fpn"]):
+            r = np.transpose(ref[j].numpy(), (0, 2, 3, 1))
+            assert np.abs(f - r).max() <= tol * max(1.0, np.abs(r).max()), (prec, j, np.abs(f - r).max())
+        m.close()
