@@ -92,6 +92,9 @@ struct ConvDesc {
   int pad_x = -1;               // horizontal padding; -1 = same as `pad`
   const void* res = nullptr;    // residual (same shape/type as out: fp32 when out_f32), added before the ReLU; unpooled only
   int ldc = 0;                  // output row pitch in elements; 0 = N
+  int row_period = 0;           // > 0 (unpooled GEMMs): output row = (q / period) * row_stride + row_offset + q % period,
+  int row_stride = 0;           //      residual row = q % period (see igemm_common.h)
+  int row_offset = 0;
   int dil = 1;                  // filter dilation
   const void* in2 = nullptr;    // optional second input: channels [Cin1, Cin) of a 1x1 conv over cat(in, in2)
   int Cin1 = 0;
@@ -186,7 +189,7 @@ struct AttnDesc {
 };
 int mhip_launch_attention(mhip_ctx* ctx, int precision, const AttnDesc& d);
 double mhip_attention_flops(const AttnDesc& d);
-int mhip_launch_patchify(mhip_ctx* ctx, int precision, const uint8_t* img, int th, int tw, int hp, int wp, int P,
+int mhip_launch_patchify(mhip_ctx* ctx, int precision, const uint8_t* imgs, int B, int th, int tw, int hp, int wp, int P,
                          int swap_rb, float mean, float stdv, void* out, int ld);
 int mhip_launch_token_init(mhip_ctx* ctx, float* x, const float* cls_row, int B, int npad, int n_tok, int D);
 int mhip_launch_tokens_to_map(mhip_ctx* ctx, int precision, const float* x, void* out, int B, int npad, int np, int D);

@@ -303,6 +303,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   // One specialised copy of the row-tile loop per (output type, residual, GELU) combination, chosen once: the loop is
   // unrolled over the 8 row-tiles (accumulators are registers), so every uniform test left inside it is replicated and
   // the kernel's code outgrows the instruction cache two CUs share — which slows the neighbour's main loop as well.
+  auto out_row = [&](int q) -> long long {
+    return p.row_period ? (long long)(q / p.row_period) * p.row_stride + p.row_offset + q % p.row_period : (long long)q;
+  };
+  auto res_row = [&](int q) -> long long { return p.row_period ? (long long)(q % p.row_period) : (long long)q; };
   auto body = [&](auto OUT32_, auto RES_, auto GELU_, auto VEC_) {
     constexpr bool OUT32 = decltype(OUT32_)::value, RES = decltype(RES_)::value, GELU = decltype(GELU_)::value,
                    VEC = decltype(VEC_)::value;
@@ -340,9 +344,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
             if (GELU)
 #pragma unroll
               for (int k = 0; k < 8; ++k) f[k] = gelu_erf(f[k]);
-            const size_t off = (size_t)q * grow + (size_t)n * 2;
+            const size_t off = (size_t)out_row(q) * grow + (size_t)n * 2;
             if (RES) {
-              const half8 r8 = *(const half8*)(p.res + off);
+              const half8 r8 = *(const half8*)(p.res + (size_t)res_row(q) * grow + (size_t)n * 2);
 #pragma unroll
               for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] + (float)r8[k], lo2);
             }
@@ -363,10 +367,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
             if (GELU)
 #pragma unroll
               for (int k = 0; k < 4; ++k) a[k] = gelu_erf(a[k]);
-            const size_t off = (size_t)q * grow + (size_t)n * oe;
+            const size_t off = (size_t)out_row(q) * grow + (size_t)n * oe;
+            const size_t roff = (size_t)res_row(q) * grow + (size_t)n * oe;
             if (VEC) {     // fp32 out
               if (RES) {
-                a += *(const float4v*)(p.res + off);
+                a += *(const float4v*)(p.res + roff);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a[k] = fmaxf(a[k], lo2);
               }
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
               for (int k = 0; k < 4; ++k)
                 if (n + k < p.N) {
                   float tv = a[k];
-                  if (p.res) tv = fmaxf(tv + (oe == 4 ? *(const float*)(p.res + off + k * 4) : (float)*(const T*)(p.res + off + k * sizeof(T))), lo2);
+                  if (p.res) tv = fmaxf(tv + (oe == 4 ? *(const float*)(p.res + roff + k * 4) : (float)*(const T*)(p.res + roff + k * sizeof(T))), lo2);
                   if (oe == 4) *(float*)(p.out + off + k * 4) = tv;
                   else *(T*)(p.out + off + k * sizeof(T)) = (T)tv;
                 }
@@ -483,6 +488,9 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.pad_x = d.pad_x >= 0 ? d.pad_x : d.pad;
   a.res = (const char*)d.res;
   a.ldc = d.ldc;
+  a.row_period = d.row_period; a.row_stride = d.row_stride; a.row_offset = d.row_offset;
+  if (d.row_period && (d.pool != POOL_NONE || d.row_period < 1 || d.row_stride < d.row_period))
+    return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: periodic row mapping needs an unpooled GEMM and stride >= period");
   a.Ho = (d.H + 2 * d.pad - a.dil * (d.KH - 1) - 1) / a.sy + 1;
   a.Wo = d.W + 2 * a.pad_x - a.dil * (d.KW - 1);
   if (a.res && d.pool != POOL_NONE) return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: a residual needs an unpooled output");

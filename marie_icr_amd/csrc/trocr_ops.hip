@@ -280,30 +280,27 @@ __global__ __launch_bounds__(CAND_T) void beam_candidates_kernel(CandArgs p) {
   const int sample = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nb = p.step == 0 ? 1 : p.beam;          // step 0: all beams are identical, only the first one competes
   const int K = 2 * p.beam;
-  // log-sum-exp per hypothesis row: ONE pass (running max + rescaled sum per thread, merged across the workgroup)
+  // log-sum-exp per hypothesis row: max pass, then sum of exp2((x - max) * log2 e) on the hardware exp unit
   for (int b = 0; b < nb; ++b) {
     const LT* row = (const LT*)p.logits + (size_t)(sample * p.beam + b) * p.ld;
-    float m = -INFINITY, s = 0.f;
-    for (int i = tid; i < p.vocab; i += CAND_T) {
-      const float x = (float)row[i];
-      if (x > m) { s = s * expf(m - x) + 1.f; m = x; }
-      else s += expf(x - m);
-    }
+    float m = -INFINITY;
+    for (int i = tid; i < p.vocab; i += CAND_T) m = fmaxf(m, (float)row[i]);
 #pragma unroll
-    for (int o = 32; o; o >>= 1) {
-      const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
-      const float mm = fmaxf(m, m2);
-      s = (m == -INFINITY ? 0.f : s * expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - mm));
-      m = mm;
-    }
-    if (lane == 0) { wred[wv] = m; wsum[wv] = s; }
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) wred[wv] = m;
+    __syncthreads();
+    m = wred[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, wred[w]);
+    float s = 0.f;
+    for (int i = tid; i < p.vocab; i += CAND_T) s += __builtin_amdgcn_exp2f(((float)row[i] - m) * 1.4426950408889634f);
+    s = wave_sum(s);
+    if (lane == 0) wsum[wv] = s;
     __syncthreads();
     if (tid == 0) {
-      float mm = wred[0];
-      for (int w = 1; w < 16; ++w) mm = fmaxf(mm, wred[w]);
       float ss = 0.f;
-      for (int w = 0; w < 16; ++w) ss += wred[w] == -INFINITY ? 0.f : wsum[w] * expf(wred[w] - mm);
-      rlse[b] = mm + logf(ss);
+      for (int w = 0; w < 16; ++w) ss += wsum[w];
+      rlse[b] = m + logf(ss);
     }
     __syncthreads();
   }

@@ -300,10 +300,13 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
   int rc;
   // patches -> hid (as the [B*np][768] patch matrix) -> x rows 1.. with bias + resized position table
   const int K0 = 3 * P * P;
-  for (int b = 0; b < B; ++b) {
-    char* A = hid + (size_t)b * g.np * K0 * es;
-    if ((rc = mhip_launch_patchify(ctx, prec, imgs + (size_t)b * th * tw * 3, th, tw, g.hp, g.wp, P, swap_rb, 127.5f, 127.5f, A, K0))) return rc;
-    if ((rc = gemm(ctx, prec, A, a.d("pe_w"), g.np, D, K0, nullptr, a.d<float>("pe_b"), x + ((size_t)b * g.npad + 1) * D, ACT_NONE, 1, pos_dev))) return rc;
+  {   // all images at once: row q of the patch matrix -> token row (q / np) * npad + 1 + q % np, + position row q % np
+    if ((rc = mhip_launch_patchify(ctx, prec, imgs, B, th, tw, g.hp, g.wp, P, swap_rb, 127.5f, 127.5f, hid, K0))) return rc;
+    ConvDesc cd;
+    cd.in = hid; cd.w = a.d("pe_w"); cd.bias = a.d<float>("pe_b"); cd.out = x; cd.res = pos_dev;
+    cd.B = 1; cd.H = 1; cd.W = B * g.np; cd.Cin = K0; cd.N = D; cd.out_f32 = 1;
+    cd.row_period = g.np; cd.row_stride = g.npad; cd.row_offset = 1;
+    if ((rc = mhip_launch_conv_igemm(ctx, prec, cd))) return rc;
   }
   if ((rc = mhip_launch_token_init(ctx, x, a.d<float>("cls"), B, g.npad, g.n_tok, D))) return rc;
   int tap_at = 0;

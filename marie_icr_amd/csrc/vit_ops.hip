@@ -280,9 +280,11 @@ __global__ __launch_bounds__(256) void attn_simple_f32_kernel(AttnArgs p, int n_
 // resized page u8 [th][tw][3] (channel order as stored; `swap_rb` selects which stored channel is model channel 0)
 // -> A[row0 + py*wp + px][k = (c*P + y)*P + x] = (pixel - mean) / std, or 0 outside (th, tw)   (zero canvas padding)
 template <typename T>
-__global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict__ img, int th, int tw, int hp, int wp,
-                                                        int P, int swap_rb, float mean, float stdv, T* __restrict__ out,
+__global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict__ imgs, int th, int tw, int hp, int wp,
+                                                        int P, int swap_rb, float mean, float stdv, T* __restrict__ outs,
                                                         int ld) {
+  const uint8_t* img = imgs + (size_t)blockIdx.y * th * tw * 3;        // image blockIdx.y of the batch
+  T* out = outs + (size_t)blockIdx.y * hp * wp * ld;
   const int kchunks = 3 * P * P / 8;                 // 8 consecutive x of one (c, y)
   const long long total = (long long)hp * wp * kchunks;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -466,11 +468,11 @@ double mhip_attention_flops(const AttnDesc& d) {
   return 4.0 * d.images * d.heads * (double)d.n_queries * d.n_keys * HD;
 }
 
-int mhip_launch_patchify(mhip_ctx* ctx, int precision, const uint8_t* img, int th, int tw, int hp, int wp, int P,
+int mhip_launch_patchify(mhip_ctx* ctx, int precision, const uint8_t* img, int B, int th, int tw, int hp, int wp, int P,
                          int swap_rb, float mean, float stdv, void* out, int ld) {
   if (P != 16 && P != 8) return mhip_fail(ctx, MHIP_EINVAL, "patchify: patch size %d", P);
   const long long total = (long long)hp * wp * (3 * P * P / 8);
-  dim3 grid(grid_for(total, 256)), block(256);
+  dim3 grid((unsigned)std::min<long long>((total + 255) / 256, 4096), B), block(256);
   if (precision == MHIP_PREC_F16)
     PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(patchify_kernel<_Float16>, grid, block, 0, ctx->stream, img, th, tw, hp, wp, P, swap_rb, mean, stdv, (_Float16*)out, ld));
   else
