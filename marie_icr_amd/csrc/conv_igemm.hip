@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 
   // ---- main loop: NSTAGE-slot ring, GL LDS-DMA instructions per wave per (half-)slice -------
   constexpr int D = C::NSTAGE - 1;  // (half-)slices in flight ahead of the one being computed
-#ifdef IGEMM_DBG_NO_LOOP
+#ifdef IGEMM_DBG_NO_LOOP   // measurement aid (profiles/r01/i_epilogue.txt): epilogue only
   const int nsteps = 0;
 #else
   const int nsteps = C::KSPLIT ? 2 * p.nslices : p.nslices;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     fill = (fill == C::NSTAGE - 1) ? 0 : fill + 1;
   }
 
-#ifdef IGEMM_DBG_NO_EPI
+#ifdef IGEMM_DBG_NO_EPI    // measurement aid: main loop only
   if (acc[0][0][0] == 123.456f) *(float*)p.out = acc[1][1][1];
   return;
 #endif
