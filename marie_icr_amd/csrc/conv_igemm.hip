@@ -193,6 +193,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       else src = ok ? a_src[q] + a_off : p.zeros;
       glds16(src, la + q * RSTEP * C::HROWB);
     }
+#ifdef IGEMM_DBG_NO_W      // measurement aid: the W slice is staged for the first slice only (wrong results, timing only)
+    if (hs > 1) return;
+#endif
+#ifdef IGEMM_DBG_NO_A
+    (void)lb;
+#endif
 #pragma unroll
     for (int q = 0; q < C::WCHUNKS; ++q) {
       const char* src = w_src[q] ? w_src[q] + w_off : p.zeros;
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     bi4[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
   }
   __syncthreads();                     // every wave is done reading the ring
-  char* wst = smem + wave * (16 * SPW);
+  char* wst0 = smem + wave * (2 * 16 * SPW);   // two private staging areas per wave: tile i+1 is written while tile i drains
   // One specialised copy of the row-tile loop per (output type, residual, GELU) combination, chosen once: the loop is
   // unrolled over the 8 row-tiles (accumulators are registers), so every uniform test left inside it is replicated and
   // the kernel's code outgrows the instruction cache two CUs share — which slows the neighbour's main loop as well.
@@ -312,6 +318,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
                    VEC = decltype(VEC_)::value;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+      char* wst = wst0 + (i & 1) * (16 * SPW);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int lc = j * 16 + frow;
@@ -389,8 +396,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
   };
   typedef std::true_type Y;
