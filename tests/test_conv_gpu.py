@@ -18,13 +18,17 @@ CASES = [
     (1, 1, 1, 256, 1, 0, 95, 0, 0, 1),       # single-row GEMM, ragged N, fp32 out
     (700, 1, 1, 512, 1, 0, 2048, 0, 0, 1),   # GEMM, many n-tiles
     (1, 40, 40, 64, 3, 1, 320, 0, 1, 0),     # 3 n-tiles with a partial one
+    (1, 1, 25000, 128, 1, 0, 768, 0, 2, 0),  # big plain GEMM + GELU M tail
+    (1, 1, 30100, 64, 1, 0, 520, 0, 1, 1),   # big GEMM, fp32 out, partial n-tile (520 = 2 x 256 + 8)
 ]
 
 
 def _ref(x, w, scale, bias, pad, pool, relu):
     y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, padding=pad)
     y = y * scale[None, :, None, None] + bias[None, :, None, None]
-    if relu:
+    if relu == 2:
+        y = F.gelu(y)
+    elif relu:
         y = F.relu(y)
     if pool == 1:
         y = F.max_pool2d(y, 2, 2)
@@ -112,3 +116,4 @@ def test_conv_dilated_and_concat_inputs(ctx):
                     db.data_ptr(), out.data_ptr(), in2_ptr=dc.data_ptr())
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
