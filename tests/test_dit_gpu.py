@@ -235,3 +235,60 @@ def test_mixed_page_sizes_interleaved(ctx, small_case):
     np.testing.assert_array_equal(first[0], again[0])
     np.testing.assert_array_equal(first[1], again[1])
     m.close()
+
+
+def test_stage_edge_cases(ctx):
+    """Zero proposals, a single proposal, levels smaller than the top-k, boxes that decode to empty."""
+    from marie_icr_amd.dit import det_final, roi_align, rpn_proposals
+    from oracle import dit_torch as dt
+
+    # no proposals at all -> no detections, no fault
+    b, s = det_final(ctx, np.zeros((0, 6), np.float32), np.zeros((0, 4), np.float32), (100, 80), (330, 255))
+    assert len(b) == 0 and len(s) == 0
+    # one proposal
+    head = np.array([[3.0, -1.0, 0.1, -0.2, 0.05, 0.3]], np.float32)
+    rois = np.array([[10, 12, 60, 40]], np.float32)
+    rb, rs = dt.fast_rcnn_inference(head, rois, (100, 80), (330, 255))
+    gb, gs = det_final(ctx, head, rois, (100, 80), (330, 255))
+    assert len(gb) == len(rb) == 1 and np.abs(gb - rb).max() <= 1e-3 and abs(gs[0] - rs[0]) <= 1e-6
+    # every score below the threshold
+    head[:, :2] = [-4.0, 4.0]
+    assert len(det_final(ctx, head, rois, (100, 80), (330, 255))[0]) == 0
+    # tiny pyramid: every level holds fewer anchors than the 1000-proposal budget; huge negative deltas collapse some boxes
+    rng = np.random.default_rng(9)
+    sizes = [(6, 5), (3, 3), (2, 2), (1, 1), (1, 1)]
+    heads = [np.concatenate([rng.normal(0, 2, (h * w, 3)), rng.normal(0, 1, (h * w, 12))], 1).astype(np.float32) for h, w in sizes]
+    heads[0][:5, 5:7] = -30.0
+    rb, rs = dt.rpn_proposals(heads, sizes, (4, 8, 16, 32, 64), (24, 20), dt.cell_anchors())
+    gb, gs = rpn_proposals(ctx, heads, sizes, (4, 8, 16, 32, 64), (24, 20))
+    np.testing.assert_array_equal(gs, rs)
+    assert np.abs(gb - rb).max() <= 1e-3
+    # ROIAlign of zero boxes
+    feats = [rng.normal(size=(h, w, 64)).astype(np.float32) for h, w in ((8, 6), (4, 3), (2, 2), (1, 1))]
+    assert roi_align(ctx, feats, np.zeros((0, 4), np.float32)).shape == (0, 49 * 64)
+
+
+def test_box_processor_small_image_is_framed(ctx, small_case):
+    """Images smaller than MIN_SIZE_TEST are framed on a white canvas (resize_image keep_max_size) and the boxes come back
+    in the ORIGINAL image's coordinates, clipped to the framed image's size as the reference does."""
+    from marie_icr_amd.box_processor import PSMode
+    from marie_icr_amd.dit_box_processor import BoxProcessorUlimDit, resize_image
+    from marie_icr_amd.weights import make_image_u8
+
+    st, *_ = small_case
+    bp = BoxProcessorUlimDit(cuda=True, state=st, model="base", precision="f16", ctx=ctx, config=_config(ctx), refinement=False)
+    img = make_image_u8(77, 1, 100, 120)[0]                      # both sides below min_size_test = 160
+    framed, coord = resize_image(img, (160, 160), keep_max_size=True)
+    assert framed.shape[:2] == (160, 160) and coord[:2] == (20, 30)
+    np.testing.assert_array_equal(framed[30:130, 20:140], img)
+    assert (framed[:30] == 255).all()
+    rects, frags, numbers, pred, lines = bp.extract_bounding_boxes("t", "k", img, PSMode.SPARSE)
+    assert len(rects) == len(frags) > 0
+    for (x, y, w, h), f in zip(rects, frags):
+        assert x >= 0 and y >= 0
+        np.testing.assert_array_equal(f, img[y:y + h, x:x + w])
+    wide = make_image_u8(78, 1, 60, 400)[0]                      # wider than min size, lower: 40 px frame left/right
+    f2, c2 = resize_image(wide, (160, 160), keep_max_size=True)
+    assert f2.shape[:2] == (160, 480) and c2[:2] == (40, 50)
+    with pytest.raises(NotImplementedError):
+        resize_image(make_image_u8(79, 1, 300, 100)[0], (160, 160), keep_max_size=True)

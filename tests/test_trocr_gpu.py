@@ -96,3 +96,20 @@ def test_f16_and_processor_surface(ctx, case):
     res16 = p16.recognize_from_fragments(frags)
     same = sum(a["text"] == b["text"] for a, b in zip(res, res16))
     assert same >= 3
+
+
+def test_single_crop_and_extreme_fragments(ctx, case):
+    """n = 1; 1-pixel-high, 1-pixel-wide and very wide fragments (Pillow-exact resize to 384 x 384 before the encoder)."""
+    from marie_icr_amd.trocr import TrOcrProcessor
+    from oracle.trocr_torch import preprocess_fragments
+
+    st, crops, o, ref, _ = case
+    rng = np.random.default_rng(8)
+    frags = [rng.integers(0, 256, size=s).astype(np.uint8) for s in ((1, 90, 3), (70, 1, 3), (12, 2300, 3))]
+    p = TrOcrProcessor(state=st, config=_cfg(ctx), precision="f32", ctx=ctx, batch_size=2)      # 2 + 1: a batch of one
+    res = p.recognize_from_fragments(frags)
+    oref = o.generate(preprocess_fragments(frags))
+    assert [r["id"] for r in res] == ["img-0", "img-1", "img-2"]
+    for r, (rt, rs) in zip(res, oref):
+        assert r["text"] == " ".join(str(int(t)) for t in rt if t not in (0, 2))
+    assert p.recognize_from_fragments([]) == []
