@@ -158,7 +158,7 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
     import threading
 
     from marie_icr_amd._lib import Context, CropDesc
-    from marie_icr_amd.dist import broadcast_arenas
+    from marie_icr_amd.dist import arenas_checksum, broadcast_arenas
     from marie_icr_amd.dit import DitModel
     from marie_icr_amd.trocr import TrocrModel, default_config as trocr_config
     from marie_icr_amd.weights import make_dit_state, make_page_bgr, make_trocr_state, page_line_boxes
@@ -182,6 +182,10 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
                 m.alloc_arena()
             with torch.cuda.stream(s_):
                 broadcast_arenas(m, c, dist, src=0)
+                sums = [None] * world
+                dist.all_gather_object(sums, arenas_checksum(m, c))
+                if len(set(sums)) != 1:
+                    raise SystemExit(f"rank {rank}: weight arenas differ across ranks after the broadcast: {sums}")
     host_pages = np.stack([make_page_bgr(1000 + rank * 97 + i, PAGE_H, PAGE_W, n_lines=LINES_PER_PAGE) for i in range(min(P, 4))])
     pages = torch.from_numpy(host_pages[np.arange(P) % len(host_pages)]).cuda()     # [P][H][W][3] in HBM
     page_bytes = PAGE_H * PAGE_W * 3
@@ -335,14 +339,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # Rehearsal of the N > 1 path on a ONE-GPU box (not for measurements): MARIE_BENCH_REHEARSE=1 puts every rank on
+    # device 0 and uses gloo for the start-up broadcast / barriers (RCCL refuses two ranks on one device).
+    rehearse = os.environ.get("MARIE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from marie_icr_amd._lib import PREC_F16, PREC_F32, Context
     from marie_icr_amd.craft import CraftModel, adjust_result_coordinates, rects_from_boxes

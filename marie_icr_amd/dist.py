@@ -70,3 +70,16 @@ def broadcast_arenas(model, ctx, dist, src: int = 0, device: str = "cuda") -> No
         ctx.synchronize()
     if device == "cuda":
         torch.cuda.synchronize()
+
+
+def arenas_checksum(model, ctx, device: str = "cuda") -> int:
+    """Sum of all arena bytes (int64) — lets every rank confirm it holds rank 0's weights after the broadcast."""
+    import torch
+
+    total = 0
+    for ptr, nbytes in model.arenas():
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ctx.memcpy_dev(buf.data_ptr(), ptr, nbytes)
+        ctx.synchronize()
+        total += int(buf.to(torch.int64).sum().item())
+    return total
