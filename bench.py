@@ -202,11 +202,12 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
 
     def detect_all():
         nb = 0
-        for s0 in range(0, P, DB):
-            ptrs = [pages.data_ptr() + pi * page_bytes for pi in range(s0, min(P, s0 + DB))]
-            for boxes, _scores in det.detect_device(ptrs, PAGE_H, PAGE_W):
-                nb += len(boxes)
-        stats["boxes"] += nb
+        for _ in range(args.det_passes):
+            for s0 in range(0, P, DB):
+                ptrs = [pages.data_ptr() + pi * page_bytes for pi in range(s0, min(P, s0 + DB))]
+                for boxes, _scores in det.detect_device(ptrs, PAGE_H, PAGE_W):
+                    nb += len(boxes)
+        stats["boxes"] += nb // args.det_passes
 
     def recognize_all():
         last[0] = rec.generate_fragments(pages.data_ptr(), descs, n_crops, swap_rb=True)
@@ -315,6 +316,10 @@ def main():
     ap.add_argument("--det-batch", type=int, default=8, help="pages per detector forward (dit_trocr)")
     ap.add_argument("--decode-len", type=int, default=15, help="generated tokens before the forced EOS (dit_trocr)")
     ap.add_argument("--model", choices=["base", "large"], default="base", help="DiT detector size (dit_trocr)")
+    ap.add_argument("--det-passes", type=int, default=1, choices=[1, 2, 3],
+                    help="detector forwards per page (dit_trocr): 1 = bbox_refinement False (the headline); 3 = the worst "
+                         "case of the reference's default refinement loop (psm_sparse re-runs the detector on the "
+                         "blacked-out page up to 3 times)")
     ap.add_argument("--crops", choices=["lines", "detector"], default="lines")
     ap.add_argument("--inflight", type=int, default=6,
                     help="page pipelines per GPU (one context + stream + host thread each): the host-side box "
