@@ -361,6 +361,20 @@ int mhip_find_line_numbers(const int32_t* lines_xywh, int n_lines, const int32_t
  * Returns MHIP_ENOMEM with *n_out = needed rows when cap is too small.                                       */
 int mhip_lines_from_bboxes(const float* xyxy, int n, int height, int width, int32_t* out_xywh, int cap, int* n_out);
 
+/* ---- page ingest (the step before the detector) ------------------------------------------------------------------------ */
+/* replaces: the shape rule of ensure_max_page_size, marie/utils/image_utils.py:275-310, for one frame (orientation-aware
+ * maximum, expanded by expand_ratio; aspect-preserving, int() truncation).  Returns 1 and the new size when the frame is
+ * too large, 0 (and the old size) when it is kept.  Host only, no ctx.                                                     */
+int mhip_max_page_size(int width, int height, int max_w_portrait, int max_h_portrait, double expand_ratio, int* new_w,
+                       int* new_h);
+/* replaces: cv2.resize(frame, (new_width, new_height), interpolation=cv2.INTER_AREA), image_utils.py:313-315 — 8-bit,
+ * 1 or 3 channels, shrinking only (dh <= sh, dw <= sw).  Device buffers; src rows src_pitch bytes apart, dst packed.        */
+int mhip_resize_area_u8(mhip_ctx* ctx, const uint8_t* src_dev, int sh, int sw, int cn, size_t src_pitch, uint8_t* dst_dev,
+                        int dh, int dw);
+/* the same on packed host buffers (stages through the context workspace). */
+int mhip_resize_area_u8_host(mhip_ctx* ctx, const uint8_t* src_host, int sh, int sw, int cn, uint8_t* dst_host, int dh,
+                             int dw);
+
 #ifdef __cplusplus
 }
 #endif
