@@ -371,6 +371,13 @@ int mhip_max_page_size(int width, int height, int max_w_portrait, int max_h_port
  * 1 or 3 channels, shrinking only (dh <= sh, dw <= sw).  Device buffers; src rows src_pitch bytes apart, dst packed.        */
 int mhip_resize_area_u8(mhip_ctx* ctx, const uint8_t* src_dev, int sh, int sw, int cn, size_t src_pitch, uint8_t* dst_dev,
                         int dh, int dw);
+/* replaces: cv2.resize(image, (new_w, new_h), interpolation=cv2.INTER_CUBIC) in resize_image's shrink branch,
+ * marie/utils/resize_image.py:53-61 (small pages / region crops framed for the DiT detector,
+ * marie/boxes/dit/ulim_dit_box_processor.py:524-540).  8-bit, 1 or 3 channels, any scale.                                  */
+int mhip_resize_cubic_u8(mhip_ctx* ctx, const uint8_t* src_dev, int sh, int sw, int cn, size_t src_pitch,
+                         uint8_t* dst_dev, int dh, int dw);
+int mhip_resize_cubic_u8_host(mhip_ctx* ctx, const uint8_t* src_host, int sh, int sw, int cn, uint8_t* dst_host, int dh,
+                              int dw);
 /* the same on packed host buffers (stages through the context workspace). */
 int mhip_resize_area_u8_host(mhip_ctx* ctx, const uint8_t* src_host, int sh, int sw, int cn, uint8_t* dst_host, int dh,
                              int dw);

@@ -98,6 +98,8 @@ _SIGNATURES = (
     ("mhip_max_page_size", _i, [_i, _i, _i, _i, C.c_double, C.POINTER(_i), C.POINTER(_i)]),
     ("mhip_resize_area_u8", _i, [_vp, _vp, _i, _i, _i, C.c_size_t, _vp, _i, _i]),
     ("mhip_resize_area_u8_host", _i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
+    ("mhip_resize_cubic_u8", _i, [_vp, _vp, _i, _i, _i, C.c_size_t, _vp, _i, _i]),
+    ("mhip_resize_cubic_u8_host", _i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     ("mhip_merge_boxes", _i, [_vp, _i, _vp, C.POINTER(_i)]),
     ("mhip_line_merge", _i, [_vp, _i, _vp, C.POINTER(_i)]),
     ("mhip_find_line_numbers", _i, [_vp, _i, _vp, _i, _vp]),

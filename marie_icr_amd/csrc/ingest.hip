@@ -112,6 +112,68 @@ __global__ __launch_bounds__(256) void resize_area_kernel(AreaArgs p) {
   for (int c = 0; c < CN; ++c) out[c] = sat_u8(sum[c]);
 }
 
+// ---- cv2.INTER_CUBIC for 8-bit images (resize_image's shrink branch, marie/utils/resize_image.py:53-61) --------------
+// OpenCV's generic separable path: per axis  f = (float)((d + 0.5) * scale - 0.5), s = floor(f), t = f - s, four taps
+// s-1 .. s+2 (replicated at the borders), Keys cubic with A = -0.75 evaluated in float32 and rounded to 11-bit fixed
+// point (x 2048, half-even); rows are combined as 32-bit integers, the result is (v + 2^21) >> 22, saturated.
+struct CubicArgs {
+  const uint8_t* src;
+  uint8_t* dst;
+  size_t src_pitch, dst_pitch;
+  int sh, sw, dh, dw;
+  double scale_x, scale_y;
+};
+
+__device__ __forceinline__ void cubic_taps(int d, double scale, int& s, int c[4]) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  const float fl = floorf(f);
+  s = (int)fl;
+  const float x = f - fl;
+  const float A = -0.75f;
+  float w[4];
+  w[0] = ((A * (x + 1.f) - 5.f * A) * (x + 1.f) + 8.f * A) * (x + 1.f) - 4.f * A;
+  w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  w[2] = ((A + 2.f) * (1.f - x) - (A + 3.f)) * (1.f - x) * (1.f - x) + 1.f;
+  w[3] = 1.f - w[0] - w[1] - w[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c[k] = (int)fminf(fmaxf(rintf(w[k] * 2048.f), -32768.f), 32767.f);
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void resize_cubic_kernel(CubicArgs p) {
+  const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dx >= p.dw || dy >= p.dh) return;
+  int sx, sy, ca[4], cb[4];
+  cubic_taps(dx, p.scale_x, sx, ca);
+  cubic_taps(dy, p.scale_y, sy, cb);
+  long long acc[CN];
+#pragma unroll
+  for (int c = 0; c < CN; ++c) acc[c] = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = min(max(sy - 1 + k, 0), p.sh - 1);
+    const uint8_t* row = p.src + (size_t)yy * p.src_pitch;
+    int h[CN];
+#pragma unroll
+    for (int c = 0; c < CN; ++c) h[c] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xx = min(max(sx - 1 + j, 0), p.sw - 1);
+#pragma unroll
+      for (int c = 0; c < CN; ++c) h[c] += (int)row[(size_t)xx * CN + c] * ca[j];
+    }
+#pragma unroll
+    for (int c = 0; c < CN; ++c) acc[c] += (long long)h[c] * cb[k];
+  }
+  uint8_t* out = p.dst + (size_t)dy * p.dst_pitch + (size_t)dx * CN;
+#pragma unroll
+  for (int c = 0; c < CN; ++c) {
+    const long long v = (acc[c] + (1ll << 21)) >> 22;
+    out[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  }
+}
+
 }  // namespace
 
 // device entry: src u8 [sh][sw][cn] (row pitch in bytes) -> dst u8 [dh][dw][cn]; both axes shrink or keep (dh <= sh, dw <= sw)
@@ -154,6 +216,45 @@ extern "C" int mhip_resize_area_u8_host(mhip_ctx* ctx, const uint8_t* src_host, 
   uint8_t* d = s + (sb + 255) / 256 * 256;
   MHIP_HIP(ctx, hipMemcpyAsync(s, src_host, sb, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = mhip_resize_area_u8(ctx, s, sh, sw, cn, (size_t)sw * cn, d, dh, dw))) return rc;
+  MHIP_HIP(ctx, hipMemcpyAsync(dst_host, d, db, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MHIP_OK;
+}
+
+// device entry: cv2.resize(src, (dw, dh), interpolation=cv2.INTER_CUBIC), u8, 1 or 3 channels, any scale
+extern "C" int mhip_resize_cubic_u8(mhip_ctx* ctx, const uint8_t* src_dev, int sh, int sw, int cn, size_t src_pitch,
+                                    uint8_t* dst_dev, int dh, int dw) {
+  if (!ctx) return MHIP_EINVAL;
+  if (!src_dev || !dst_dev) return mhip_fail(ctx, MHIP_EINVAL, "resize_cubic: null buffer");
+  if (cn != 1 && cn != 3) return mhip_fail(ctx, MHIP_EINVAL, "resize_cubic: %d channels (1 or 3)", cn);
+  if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) return mhip_fail(ctx, MHIP_EINVAL, "resize_cubic: empty image");
+  if (src_pitch < (size_t)sw * cn) return mhip_fail(ctx, MHIP_EINVAL, "resize_cubic: source pitch below the row size");
+  CubicArgs a;
+  a.src = src_dev; a.dst = dst_dev;
+  a.src_pitch = src_pitch; a.dst_pitch = (size_t)dw * cn;
+  a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw;
+  a.scale_x = 1.0 / ((double)dw / sw); a.scale_y = 1.0 / ((double)dh / sh);
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  dim3 grid((unsigned)((dw + 63) / 64), (unsigned)((dh + 3) / 4)), block(256);
+  if (cn == 1) PROF_LAUNCH(ctx, MHIP_K_IMAGE_OPS, hipLaunchKernelGGL(resize_cubic_kernel<1>, grid, block, 0, ctx->stream, a));
+  else PROF_LAUNCH(ctx, MHIP_K_IMAGE_OPS, hipLaunchKernelGGL(resize_cubic_kernel<3>, grid, block, 0, ctx->stream, a));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "resize_cubic launch: %s", hipGetErrorString(e));
+  return MHIP_OK;
+}
+
+extern "C" int mhip_resize_cubic_u8_host(mhip_ctx* ctx, const uint8_t* src_host, int sh, int sw, int cn, uint8_t* dst_host,
+                                         int dh, int dw) {
+  if (!ctx || !src_host || !dst_host) return MHIP_EINVAL;
+  if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || (cn != 1 && cn != 3)) return mhip_fail(ctx, MHIP_EINVAL, "resize_cubic: bad shape");
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t sb = (size_t)sh * sw * cn, db = (size_t)dh * dw * cn;
+  int rc = mhip_ensure_workspace(ctx, sb + db + 1024);
+  if (rc) return rc;
+  uint8_t* s = (uint8_t*)ctx->ws;
+  uint8_t* d = s + (sb + 255) / 256 * 256;
+  MHIP_HIP(ctx, hipMemcpyAsync(s, src_host, sb, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = mhip_resize_cubic_u8(ctx, s, sh, sw, cn, (size_t)sw * cn, d, dh, dw))) return rc;
   MHIP_HIP(ctx, hipMemcpyAsync(dst_host, d, db, hipMemcpyDeviceToHost, ctx->stream));
   MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MHIP_OK;

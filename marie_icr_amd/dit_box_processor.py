@@ -7,8 +7,7 @@ Mirrors marie/boxes/dit/ulim_dit_box_processor.py:358-832: same constructor argu
 blackout and the box/line geometry run in libmarie_hip.so; this file is the control flow between them.
 
 Not carried over: ``bbox_optimization`` (``crop_to_content_box``: OpenCV Otsu / GaussianBlur / morphology — off by default
-in the reference and in every caller on the hot path) raises NotImplementedError, as does ``resize_image``'s INTER_CUBIC
-shrink branch for inputs that are taller than MIN_SIZE_TEST but narrower (marie/utils/resize_image.py:53-61).
+in the reference and in every caller on the hot path) raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -24,8 +23,11 @@ from .dit import DitModel
 from .geometry import find_line_numbers, lines_from_bboxes, merge_boxes
 
 
-def resize_image(image: np.ndarray, desired_size, color=(255, 255, 255), keep_max_size: bool = False):
-    """The padding branches of marie/utils/resize_image.py:9-76 (``cv2.copyMakeBorder`` with a constant colour)."""
+def resize_image(image: np.ndarray, desired_size, color=(255, 255, 255), keep_max_size: bool = False,
+                 ctx: Optional[Context] = None):
+    """marie/utils/resize_image.py:9-76: frame ``image`` on a ``desired_size`` (height, width) canvas of ``color``; an image
+    larger than the canvas on either side is first shrunk, aspect kept, with cv2.INTER_CUBIC — here the HIP kernel
+    ``mhip_resize_cubic_u8`` (``ctx`` required for that branch only).  Returns ``(image, (x, y, w, h))``."""
     if image.shape[0] == desired_size[0] and image.shape[1] == desired_size[1]:
         return image, (0, 0, image.shape[1], image.shape[0])
     size = image.shape[:2]
@@ -46,7 +48,19 @@ def resize_image(image: np.ndarray, desired_size, color=(255, 255, 255), keep_ma
             size = image.shape[:2]
             return image, (40, top, size[1], size[0])
     if size[0] > desired_size[0] or size[1] > desired_size[1]:
-        raise NotImplementedError("resize_image: the cv2.INTER_CUBIC shrink branch is not part of this build")
+        if ctx is None:
+            raise MarieHipError("resize_image: the INTER_CUBIC shrink runs on the GPU and needs a Context")
+        ratio = min(float(desired_size[0]) / size[0], float(desired_size[1]) / size[1])
+        new_size = tuple(int(x * ratio) for x in size)
+        if new_size[0] < 1 or new_size[1] < 1:
+            raise ValueError(f"resize_image: {size} does not fit {tuple(desired_size)}")
+        src = np.ascontiguousarray(image, np.uint8)
+        out = np.empty((new_size[0], new_size[1], src.shape[2]), np.uint8)
+        check(ctx.h, ctx.lib.mhip_resize_cubic_u8_host(ctx.h, src.ctypes.data_as(C.c_void_p), src.shape[0], src.shape[1],
+                                                       src.shape[2], out.ctypes.data_as(C.c_void_p), out.shape[0],
+                                                       out.shape[1]), "mhip_resize_cubic_u8_host")
+        image = out
+        size = image.shape
     delta_w = max(0, desired_size[1] - size[1])
     delta_h = max(0, desired_size[0] - size[0])
     top, bottom = delta_h // 2, delta_h - (delta_h // 2)
@@ -139,7 +153,8 @@ class BoxProcessorUlimDit:
         """reference: ulim_dit_box_processor.py:499-658."""
         adj_x = adj_y = 0
         if image.shape[0] < self.min_size_test[0] or image.shape[1] < self.min_size_test[1]:
-            image, coord = resize_image(image, (self.min_size_test[0], self.min_size_test[1]), keep_max_size=True)
+            image, coord = resize_image(image, (self.min_size_test[0], self.min_size_test[1]), keep_max_size=True,
+                                        ctx=self.ctx)
             adj_x, adj_y = coord[0], coord[1]
         refinement = self.refinement if bbox_refinement is None else bbox_refinement
         refinement_steps = 3 if refinement else 1

@@ -1,6 +1,7 @@
 """ORACLE (test infrastructure, not product code) — CPU restatement of the page-size clamp the reference applies before OCR:
 ``ensure_max_page_size`` (marie/utils/image_utils.py:254-321) and the ``cv2.resize(..., interpolation=cv2.INTER_AREA)`` it
-calls (:313-315).
+calls (:313-315); and of ``resize_image`` (marie/utils/resize_image.py:9-76) with its ``cv2.INTER_CUBIC`` shrink, which
+frames small pages / region crops for the DiT detector (marie/boxes/dit/ulim_dit_box_processor.py:524-540).
 
 Pinning: the SHAPE RULE is pinned by the reference's own tests (tests/imaging/test_image_resizing.py:7-34: three cases
 agree with the reference's code; the fourth, ``test_max_page_001`` :37-44, expects (3200, 2600) for a 4171 x 2569 frame,
@@ -130,3 +131,80 @@ def ensure_max_page_size(frames: List[np.ndarray], max_page_size_: Tuple[int, in
         else:
             out.append(frame)
     return changed, out
+
+
+# ---------------------------------------------------------------------------------------------- cv2.INTER_CUBIC (8-bit)
+def _cubic_tab(dsize: int, scale: float):
+    """per destination index: first tap's source index - 1 ... and four 11-bit fixed-point Keys (A = -0.75) weights, the
+    way OpenCV's resize() fills xofs / ialpha: float32 polynomial, x 2048, round half to even."""
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    fl = np.floor(f)
+    x = (f - fl).astype(np.float32)
+    one, A = np.float32(1.0), np.float32(-0.75)
+    x1 = x + one
+    w0 = ((A * x1 - np.float32(5.0) * A) * x1 + np.float32(8.0) * A) * x1 - np.float32(4.0) * A
+    w1 = ((A + np.float32(2.0)) * x - (A + np.float32(3.0))) * x * x + one
+    xm = one - x
+    w2 = ((A + np.float32(2.0)) * xm - (A + np.float32(3.0))) * xm * xm + one
+    w3 = one - w0 - w1 - w2
+    w = np.stack([w0, w1, w2, w3], axis=1).astype(np.float32)
+    coef = np.clip(np.rint(w * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+    return fl.astype(np.int64), coef
+
+
+def resize_cubic(img: np.ndarray, new_width: int, new_height: int) -> np.ndarray:
+    """cv2.resize(img, (new_width, new_height), interpolation=cv2.INTER_CUBIC) for uint8 HxW / HxWx{1,3}: OpenCV's generic
+    separable fixed-point path (integer row combination, (v + 2^21) >> 22, saturate).  PARITY UNPINNED (see the module
+    header); x86 builds of OpenCV combine the rows of 8-pixel groups in float32 instead, which can differ by one level."""
+    src = img if img.ndim == 3 else img[:, :, None]
+    sh, sw, cn = src.shape
+    dh, dw = int(new_height), int(new_width)
+    sx, ca = _cubic_tab(dw, 1.0 / (dw / sw))
+    sy, cb = _cubic_tab(dh, 1.0 / (dh / sh))
+    s64 = src.astype(np.int64)
+    hor = np.zeros((sh, dw, cn), np.int64)
+    for j in range(4):
+        xx = np.clip(sx - 1 + j, 0, sw - 1)
+        hor += s64[:, xx, :] * ca[None, :, j, None]
+    assert np.abs(hor).max() < 2 ** 31
+    acc = np.zeros((dh, dw, cn), np.int64)
+    for k in range(4):
+        yy = np.clip(sy - 1 + k, 0, sh - 1)
+        acc += hor[yy] * cb[:, k, None, None]
+    out = np.clip((acc + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+    return out if img.ndim == 3 else out[:, :, 0]
+
+
+def resize_image(image: np.ndarray, desired_size, color=(255, 255, 255), keep_max_size: bool = False):
+    """marie/utils/resize_image.py:9-76 -> (image, (x, y, w, h))."""
+    if image.shape[0] == desired_size[0] and image.shape[1] == desired_size[1]:
+        return image, (0, 0, image.shape[1], image.shape[0])
+    size = image.shape[:2]
+
+    def border(img, top, bottom, left, right):
+        out = np.empty((img.shape[0] + top + bottom, img.shape[1] + left + right) + img.shape[2:], img.dtype)
+        out[...] = np.asarray(color, img.dtype) if img.ndim == 3 else color[0]
+        out[top:top + img.shape[0], left:left + img.shape[1]] = img
+        return out
+
+    if keep_max_size:
+        h, w = size
+        dh, dw = desired_size
+        if w > dw and h < dh:
+            delta_h = max(0, desired_size[0] - size[0])
+            top, bottom = delta_h // 2, delta_h - (delta_h // 2)
+            image = border(image, top, bottom, 40, 40)
+            size = image.shape[:2]
+            return image, (40, top, size[1], size[0])
+    if size[0] > desired_size[0] or size[1] > desired_size[1]:
+        ratio = min(float(desired_size[0]) / size[0], float(desired_size[1]) / size[1])
+        new_size = tuple(int(x * ratio) for x in size)
+        image = resize_cubic(image, new_size[1], new_size[0])
+        size = image.shape
+    delta_w = max(0, desired_size[1] - size[1])
+    delta_h = max(0, desired_size[0] - size[0])
+    top, bottom = delta_h // 2, delta_h - (delta_h // 2)
+    left, right = delta_w // 2, delta_w - (delta_w // 2)
+    image = border(image, top, bottom, left, right)
+    return image, (left, top, size[1], size[0])

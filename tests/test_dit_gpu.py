@@ -290,5 +290,13 @@ def test_box_processor_small_image_is_framed(ctx, small_case):
     wide = make_image_u8(78, 1, 60, 400)[0]                      # wider than min size, lower: 40 px frame left/right
     f2, c2 = resize_image(wide, (160, 160), keep_max_size=True)
     assert f2.shape[:2] == (160, 480) and c2[:2] == (40, 50)
-    with pytest.raises(NotImplementedError):
-        resize_image(make_image_u8(79, 1, 300, 100)[0], (160, 160), keep_max_size=True)
+    # taller than the canvas but narrower: shrunk with INTER_CUBIC (aspect kept), then framed (resize_image.py:53-76)
+    from oracle import ingest_ref
+
+    tall = make_image_u8(79, 1, 300, 100)[0]
+    f3, c3 = resize_image(tall, (160, 160), keep_max_size=True, ctx=ctx)
+    r3, rc3 = ingest_ref.resize_image(tall, (160, 160), keep_max_size=True)
+    assert f3.shape == r3.shape == (160, 160, 3) and tuple(c3) == tuple(rc3) == (53, 0, 53, 160)
+    np.testing.assert_array_equal(f3, r3)
+    rects, frags, *_ = bp.extract_bounding_boxes("t", "k", tall, PSMode.SPARSE)      # the whole path accepts such a page
+    assert len(rects) == len(frags)

@@ -82,3 +82,25 @@ def test_page_feeder_overlaps_and_preserves_bytes(ctx):
     assert feeder.bytes_moved == sum(len(b) for b in batches) * H * W * 3
     for bi, i, dst in outs:
         assert np.array_equal(dst.cpu().numpy(), ingest_ref.resize_area(batches[bi][i], W // 2, H // 2)), (bi, i)
+
+
+@pytest.mark.parametrize("shape,new_wh", [
+    ((97, 131, 3), (120, 90)),        # mild shrink
+    ((300, 100, 3), (53, 160)),       # resize_image's case: ratio 0.533
+    ((64, 64), (23, 17)),             # gray, strong shrink (taps skip pixels, as in OpenCV)
+    ((40, 50, 3), (125, 100)),        # enlarge 2.5 x: borders replicate
+    ((31, 33, 3), (33, 31)),          # identity: weights (0, 2048, 0, 0)
+    ((5, 3), (1, 1)),
+])
+def test_resize_cubic_bit_exact(ctx, shape, new_wh):
+    img = np.random.default_rng(sum(shape) + 1).integers(0, 256, shape, dtype=np.uint8)
+    src = np.ascontiguousarray(img)
+    cn = 1 if src.ndim == 2 else 3
+    out = np.empty((new_wh[1], new_wh[0]) + (() if src.ndim == 2 else (3,)), np.uint8)
+    check(ctx.h, ctx.lib.mhip_resize_cubic_u8_host(ctx.h, src.ctypes.data_as(C.c_void_p), src.shape[0], src.shape[1], cn,
+                                                   out.ctypes.data_as(C.c_void_p), out.shape[0], out.shape[1]),
+          "mhip_resize_cubic_u8_host")
+    ref = ingest_ref.resize_cubic(img, *new_wh)
+    assert np.array_equal(out, ref), int(np.abs(out.astype(int) - ref.astype(int)).max())
+    if shape[:2] == (new_wh[1], new_wh[0]):
+        assert np.array_equal(out, img)

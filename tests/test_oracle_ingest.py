@@ -90,3 +90,29 @@ def test_load_image_bursts_tiff(tmp_path):
     assert ingest.load_image(None) == (False, None)
     with pytest.raises(NotImplementedError):
         ingest.load_image("x.pdf")
+
+
+def test_cubic_resampler_properties():
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    assert np.array_equal(ingest_ref.resize_cubic(img, 56, 40), img)                    # scale 1: taps (0, 2048, 0, 0)
+    const = np.full((30, 44), 77, np.uint8)
+    assert (ingest_ref.resize_cubic(const, 17, 11) == 77).all() and (ingest_ref.resize_cubic(const, 90, 61) == 77).all()
+    _, coef = ingest_ref._cubic_tab(97, 1.0 / (97 / 131))
+    assert np.all(np.abs(coef.sum(axis=1) - 2048) <= 2)                                 # weights sum to ~1 in 11-bit fixed point
+    ramp = np.clip(np.add.outer(np.arange(60) * 3, np.arange(80) * 1), 0, 255).astype(np.uint8)
+    small = ingest_ref.resize_cubic(ramp, 40, 30).astype(int)
+    exact = np.add.outer(((np.arange(30) + 0.5) * 2 - 0.5) * 3, ((np.arange(40) + 0.5) * 2 - 0.5) * 1)
+    inner = (slice(2, -2), slice(2, -2))
+    assert np.abs(small[inner] - exact[inner]).max() <= 1.0                             # a cubic reproduces linear ramps
+
+
+def test_resize_image_oracle_branches():
+    img = np.random.default_rng(4).integers(0, 256, (100, 120, 3), dtype=np.uint8)
+    framed, coord = ingest_ref.resize_image(img, (160, 160), keep_max_size=True)
+    assert framed.shape == (160, 160, 3) and coord == (20, 30, 120, 100) and np.array_equal(framed[30:130, 20:140], img)
+    same, c0 = ingest_ref.resize_image(img, (100, 120))
+    assert same is img and c0 == (0, 0, 120, 100)
+    tall = np.random.default_rng(5).integers(0, 256, (300, 100, 3), dtype=np.uint8)
+    f3, c3 = ingest_ref.resize_image(tall, (160, 160), keep_max_size=True)
+    assert f3.shape == (160, 160, 3) and c3 == (53, 0, 53, 160) and (f3[:, :53] == 255).all()

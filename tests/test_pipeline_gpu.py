@@ -170,3 +170,47 @@ def test_voting_engine_two_recognizers_one_detection(ctx):
         assert w["processor"] in ("default", "craft")
         if w["strategy"]["type"] == "default":
             assert w["text"] == ra[w["id"]]["text"]
+
+
+def test_mixed_dpi_pages_interleaved_through_ingest_and_engine(ctx):
+    """BASELINE configs[4] as a parity case: pages scanned at 150 / 200 / 300 DPI (sizes 1 : 4/3 : 2) interleaved in one
+    call, one of them over the page-size limit.  ``ensure_max_page_size`` clamps only that one; the engine's result for
+    every page equals the result of that page processed alone (no cross-page state in the detector batch, the crop
+    batcher or the recognizer's decoding batch), and the recognizer sees crops of all three scales in one batch."""
+    from marie_icr_amd import ingest
+    from marie_icr_amd.box_processor import PSMode
+    from marie_icr_amd.dit import default_config as dit_config
+    from marie_icr_amd.dit_box_processor import BoxProcessorUlimDit
+    from marie_icr_amd.ocr_engine import CoordinateFormat, MarieHipOcrEngine
+    from marie_icr_amd.trocr import TrOcrProcessor, default_config as trocr_config
+    from marie_icr_amd.weights import make_dit_state, make_image_u8, make_trocr_state
+    from oracle import ingest_ref
+
+    dcfg = dit_config(ctx.lib, "base")
+    dcfg.min_size_test, dcfg.max_size_test = 160, 400
+    enc, dec = (256, 2, 4), (256, 2, 4, 512)
+    tcfg = trocr_config(ctx.lib, "base")
+    tcfg.enc_dim, tcfg.enc_depth, tcfg.enc_heads = enc
+    tcfg.dec_dim, tcfg.dec_layers, tcfg.dec_heads, tcfg.dec_ffn = dec
+    tcfg.vocab, tcfg.max_positions, tcfg.max_len_b = 97, 32, 8
+    box = BoxProcessorUlimDit(cuda=True, state=make_dit_state(0), model="base", precision="f16", ctx=ctx, config=dcfg,
+                              refinement=False)
+    rec = TrOcrProcessor(state=make_trocr_state(0, enc, dec, 97, 32), config=tcfg, precision="f16", ctx=ctx)
+    eng = MarieHipOcrEngine(box_processor=box, default_ocr_processor=rec)
+    sizes = [(200, 160), (266, 213), (400, 320), (266, 213), (200, 160), (520, 400)]       # the last one is oversized
+    frames = [make_image_u8(40 + i, 1, h, w)[0] for i, (h, w) in enumerate(sizes)]
+    limit = (320, 400)                                                                     # (width, height) portrait
+    changed, clamped = ingest.ensure_max_page_size(frames, max_page_size=limit, expand_ratio=0.0, ctx=ctx)
+    assert changed is True
+    assert all(c is f for c, f in zip(clamped[:5], frames[:5]))
+    ref_changed, ref = ingest_ref.ensure_max_page_size(frames, limit, 0.0)
+    assert ref_changed and clamped[5].shape == ref[5].shape == (400, 307, 3) and np.array_equal(clamped[5], ref[5])
+    together = eng.extract(clamped, PSMode.SPARSE, CoordinateFormat.XYWH)
+    assert len(together) == len(clamped)
+    for i, page in enumerate(clamped):
+        alone = eng.extract([page], PSMode.SPARSE, CoordinateFormat.XYWH)[0]
+        a = [(tuple(int(v) for v in w["box"]), w["text"], w["line"]) for w in alone["words"]]
+        t = [(tuple(int(v) for v in w["box"]), w["text"], w["line"]) for w in together[i]["words"]]
+        assert a == t and len(a) > 0, i
+        assert np.allclose([w["confidence"] for w in alone["words"]], [w["confidence"] for w in together[i]["words"]], atol=2e-3)
+    assert together[0]["meta"]["imageSize"]["width"] == 160 and together[2]["meta"]["imageSize"]["width"] == 320
