@@ -113,3 +113,35 @@ def test_single_crop_and_extreme_fragments(ctx, case):
     for r, (rt, rs) in zip(res, oref):
         assert r["text"] == " ".join(str(int(t)) for t in rt if t not in (0, 2))
     assert p.recognize_from_fragments([]) == []
+
+
+@pytest.mark.parametrize("enc,dec,vocab,maxpos,beam", [
+    ((256, 2, 4), (512, 2, 8, 640), 203, 24, 3),      # encoder narrower than the decoder (as trocr-base: 768 vs 1024)
+    ((512, 1, 8), (256, 3, 4, 384), 61, 20, 4),       # encoder wider than the decoder, beam 4, short dictionary
+    ((768, 1, 12), (1024, 1, 16, 1024), 1031, 16, 2), # the released base widths (one layer each), prime vocabulary, beam 2
+])
+def test_fp32_parity_with_unequal_encoder_and_decoder_widths(ctx, enc, dec, vocab, maxpos, beam):
+    """Cross-attention projects encoder tokens of one width into a decoder of another (kdim / vdim = encoder width, as in
+    every released TrOCR model); head counts, FFN widths, vocabulary sizes and beam widths away from the defaults."""
+    from marie_icr_amd._lib import PREC_F32
+    from marie_icr_amd.trocr import TrocrModel, default_config
+    from marie_icr_amd.weights import make_image_u8, make_trocr_state
+    from oracle.trocr_torch import TorchTrocrOracle
+
+    st = make_trocr_state(5, enc, dec, vocab, maxpos)
+    crops = make_image_u8(31, 5, 384, 384)
+    max_len_b = min(10, maxpos - 4)
+    o = TorchTrocrOracle(st, enc[2], dec[2], beam=beam, max_len_b=max_len_b)
+    ref, step0 = o.generate(crops, want_step0=True)
+    cfg = default_config(ctx.lib, "base")
+    cfg.enc_dim, cfg.enc_depth, cfg.enc_heads = enc
+    cfg.dec_dim, cfg.dec_layers, cfg.dec_heads, cfg.dec_ffn = dec
+    cfg.vocab, cfg.max_positions, cfg.beam, cfg.max_len_b = vocab, maxpos, beam, max_len_b
+    m = TrocrModel(ctx, st, cfg, PREC_F32)
+    got, encoded, lg = m.generate_host(crops, want_taps=True)
+    assert np.abs(encoded - o.encode(crops).numpy()).max() <= 1e-3
+    assert np.abs(lg - step0).max() <= 2e-3
+    for (gt, gs), (rt, rs) in zip(got, ref):
+        np.testing.assert_array_equal(gt, rt)
+        assert abs(gs - rs) <= 1e-3
+    m.close()
