@@ -484,3 +484,43 @@ def make_trocr_state(seed: int = 0, enc=(768, 12, 12), dec=(1024, 12, 16, 4096),
         st[f"decoder.layers.{L - 1}.final_layer_norm.bias"] = b
         st["decoder.embed_tokens.weight"][eos] += b * np.float32(eos_gain / float((b * b).sum()))
     return st
+
+
+def make_ocr_result(seed: int, width: int, height: int, n_lines: int = 12, page: int = 0) -> dict:
+    """A seeded page result in the engine's output layout (``{"meta", "words", "lines"}``, boxes xywh) — synthetic input
+    for the step after the path (renderers, ``get_words_and_boxes``): ragged lines, gaps, words of 1..12 characters."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    alphabet = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789-.,#$%/"
+    words, lines = [], []
+    wid = 0
+    y = int(rng.integers(10, 60))
+    for ln in range(1, n_lines + 1):
+        lh = int(rng.integers(18, 40))
+        if y + lh >= height - 4:
+            break
+        x = int(rng.integers(0, max(1, width // 3)))
+        ids, x0 = [], None
+        k = 0
+        while True:
+            n_ch = int(rng.integers(1, 13))
+            ww = int(n_ch * rng.integers(7, 12))
+            if x + ww >= width - 2 or k >= 14:
+                break
+            text = "".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), n_ch))
+            words.append({"id": wid, "text": text, "confidence": round(float(rng.uniform(0.3, 1.0)), 4),
+                          "box": [x, y + int(rng.integers(0, 4)), ww, lh - int(rng.integers(0, 4))], "line": ln,
+                          "word_index": k})
+            ids.append(wid)
+            x0 = x if x0 is None else x0
+            wid += 1
+            k += 1
+            x += ww + int(rng.integers(4, 90))
+        if ids:
+            last = words[ids[-1]]["box"]
+            lines.append({"line": ln, "wordids": ids, "text": " ".join(words[i]["text"] for i in ids),
+                          "bbox": [x0, y, last[0] + last[2] - x0, lh], "confidence": 1.0})
+        y += lh + int(rng.integers(2, 70))
+    order = rng.permutation(len(words))                      # the engine does not promise id order in "words"
+    return {"meta": {"imageSize": {"width": int(width), "height": int(height)}, "page": int(page), "lang": "en",
+                     "format": "xywh"},
+            "words": [words[int(i)] for i in order], "lines": lines}

@@ -306,9 +306,77 @@ def gen_vit(out_dir):
         print("vit", tag, [o.shape for o in outs], [float(np.abs(o).max()) for o in outs])
 
 
+RENDER_CASES = ((0, 850, 1100, 14), (1, 2550, 3300, 40), (2, 1700, 600, 9), (3, 640, 480, 3), (4, 1275, 1650, 0))
+
+
+def _load_ref_text_renderer():
+    """marie/renderer/renderer.py and text_renderer.py, unmodified, by path.  Their package imports are satisfied by
+    placeholders: ``marie.logging_core.logger.MarieLogger`` (a silent logger), ``marie.renderer`` (exposing the
+    ``ResultRenderer`` just loaded) and ``marie.utils.types.strtobool`` (not reached: no config key is set)."""
+    import importlib.util
+    import types
+
+    class _Quiet:
+        def __init__(self, *a, **k):
+            pass
+
+        def info(self, *a, **k):
+            pass
+
+        error = warning = debug = info
+
+    for name in ("marie", "marie.logging_core", "marie.logging_core.logger", "marie.utils", "marie.utils.types", "marie.renderer"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["marie.logging_core.logger"].MarieLogger = _Quiet
+    sys.modules["marie.utils.types"].strtobool = lambda v: v if isinstance(v, bool) else str(v).lower() in ("1", "true", "yes", "y", "on")
+    base = "/root/reference/marie/renderer/"
+    spec = importlib.util.spec_from_file_location("ref_renderer_base", base + "renderer.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sys.modules["marie.renderer"].ResultRenderer = mod.ResultRenderer
+    spec = importlib.util.spec_from_file_location("ref_text_renderer", base + "text_renderer.py")
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    return tr.TextRenderer
+
+
+def gen_renderer(out_dir):
+    """Text the reference's own TextRenderer writes for seeded page results (the step after the path)."""
+    import contextlib
+    import copy
+    import io
+    import json
+    import tempfile
+
+    from marie_icr_amd.weights import make_ocr_result
+
+    TextRenderer = _load_ref_text_renderer()
+    cases = []
+    with tempfile.TemporaryDirectory() as td:
+        def run(frames, results):
+            path = os.path.join(td, "out.txt")
+            with contextlib.redirect_stdout(io.StringIO()):          # the reference prints its grid while rendering
+                TextRenderer(config={}).render(frames, copy.deepcopy(results), path)
+            with open(path, encoding="UTF-8") as f:
+                return f.read()
+
+        for seed, w, h, n in RENDER_CASES:
+            res = make_ocr_result(seed, w, h, n)
+            cases.append({"seed": seed, "width": w, "height": h, "n_lines": n,
+                          "text": run([np.zeros((h, w, 3), np.uint8)], [res])})
+        multi = [make_ocr_result(10 + i, 900, 700, 6, page=i) for i in range(3)]
+        doc = run([np.zeros((700, 900, 3), np.uint8)] * 3, multi)
+    with open(os.path.join(out_dir, "text_renderer.json"), "w", encoding="UTF-8") as f:
+        json.dump({"cases": cases, "multi_page": {"seeds": [10, 11, 12], "width": 900, "height": 700, "n_lines": 6, "text": doc}}, f)
+    print("renderer", [len(c["text"]) for c in cases], len(doc))
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if "--renderer-only" in sys.argv:
+        gen_renderer(out_dir)
+        return
     if "--vit-only" in sys.argv:
         gen_vit(out_dir)
         return
