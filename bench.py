@@ -152,6 +152,17 @@ def cpu_baseline_dit_trocr(dit_state, trocr_state, trocr_dims, decode_len, n_lin
                       f"({(t3 - t2) / k:.2f} s/crop, beam 3, {decode_len}+1 steps), recognizer time scaled to {n_lines} crops"}
 
 
+def _pmc_traffic(config):
+    """profiles/r01/p_pmc_traffic.json (rocprofv3 --pmc passes folded by tools/pmc_traffic.py) if it was taken on `config`."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "p_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return d if d.get("config") == config else None
+
+
 def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
     """BASELINE configs[2]: DiT-base detector + TrOCR-base recognizer, full pages, one GPU per rank."""
     import ctypes as C
@@ -318,6 +329,14 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
             "measured": "HIP events on the launch streams, detector then recognizer alone, same step right after the "
                         "timed region; FLOPs = 2*MAC of every launch (mhip_profile_flops)",
         }
+        # HBM-side bytes per launch: PMC counters cannot be read from inside this process, so the committed result of
+        # the rocprofv3 --pmc passes over this same configuration is reported (null for any other configuration)
+        pmc = _pmc_traffic({"workload": "dit_trocr", "pages": P, "det_batch": DB, "decode_len": args.decode_len,
+                            "model": args.model, "det_passes": args.det_passes, "precision": args.precision})
+        if pmc is not None and "conv_igemm" in pmc["kernels"]:
+            out["roofline"]["traffic"] = pmc["kernels"]["conv_igemm"]["bytes_per_launch"]
+            out["roofline"]["traffic_unit"] = ("bytes per launch, HBM side (FETCH_SIZE x 2 + WRITE_SIZE; "
+                                               "profiles/r01/p_pmc_traffic.json)")
         a = prof["attn_flash"]
         out["roofline_attention"] = {"kernel": "attn_flash", "bound": "mfma",
                                      "achieved": a["flops"] / (a["total_ms"] * 1e-3) / 1e12 if a["total_ms"] > 0 else 0.0,
