@@ -27,6 +27,8 @@ enum MhipKernelId {
   MHIP_K_COUNT = 12
 };
 
+constexpr int MHIP_ZERO_BYTES = 65536;
+
 struct ProfSlot {
   double total_ms = 0.0;
   int64_t launches = 0;
@@ -41,7 +43,7 @@ struct mhip_ctx {
   // workspace (grown on demand, never inside a steady-state forward)
   void* ws = nullptr;
   size_t ws_bytes = 0;
-  void* zeros = nullptr;  // 4 KiB of zeros: source of padding taps for LDS-DMA loads
+  void* zeros = nullptr;  // MHIP_ZERO_BYTES of zeros: source of padding taps / rows beyond M, N for LDS-DMA loads
   bool profiling = false;
   ProfSlot prof[MHIP_K_COUNT];
   std::vector<hipEvent_t> event_pool;

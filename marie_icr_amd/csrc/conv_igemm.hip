@@ -173,14 +173,44 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     w_src[q] = (n < p.N) ? p.w + ((size_t)n * p.Ktot + (size_t)lchunk * E) * sizeof(T) : nullptr;
   }
 
-  auto stage = [&](int hs, int slot) {
+  // Plain GEMMs (1x1, unpadded, unstrided, one input — every ViT / decoder product): slice `it` of chunk q is simply
+  // a_src[q] + 128 it, so the pointers are advanced in place and a slice costs 2 VALU + 2 SALU per DMA instruction.  Rows
+  // beyond M / N walk through the zero page instead (it holds a whole K row).  The general path below recomputes the tap
+  // and the bounds of every chunk for every slice (~130 instructions per wave and slice, issued by both waves of a SIMD
+  // right after the barrier, when nobody has MFMA work yet).
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const bool pure = !DUAL && !C::KSPLIT && POOL == POOL_NONE && p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 &&
+                    p.sy == 1 && (size_t)p.Ktot * sizeof(T) + ROWB <= (size_t)MHIP_ZERO_BYTES;
+  if (pure) {
+#pragma unroll
+    for (int q = 0; q < C::ACHUNKS; ++q)
+      if (m0 + q * RSTEP + srow >= p.M) a_src[q] = p.zeros + lchunk * 16;
+#pragma unroll
+    for (int q = 0; q < C::WCHUNKS; ++q)
+      if (!w_src[q]) w_src[q] = p.zeros + lchunk * 16;
+  }
+  auto stage_pure = [&](int slot) {      // called once per slice, in K order
+    char* la = smem + slot * C::STAGE_BYTES + wave_s * RPI * C::HROWB;
+    char* lb = la + A_BYTES;
+#pragma unroll
+    for (int q = 0; q < C::ACHUNKS; ++q) {
+      glds16(a_src[q], la + q * RSTEP * C::HROWB);
+      a_src[q] += ROWB;
+    }
+#pragma unroll
+    for (int q = 0; q < C::WCHUNKS; ++q) {
+      glds16(w_src[q], lb + q * RSTEP * C::HROWB);
+      w_src[q] += ROWB;
+    }
+  };
+  auto stage_general = [&](int hs, int slot) {
     const int it = C::KSPLIT ? (hs >> 1) : hs;            // K slice
     const int hoff = C::KSPLIT ? (hs & 1) * 64 : 0;       // byte offset of the k-group half inside the slice
     int tap = it / p.cpt, cc = it - tap * p.cpt;
     int dy = (tap / p.KW) * p.dil, dx = (tap - (tap / p.KW) * p.KW) * p.dil;
     size_t a_off = (((size_t)dy * p.W + dx) * p.Cin + (size_t)cc * BKE) * sizeof(T) + hoff;
     size_t w_off = (size_t)it * BKE * sizeof(T) + hoff;
-    char* la = smem + slot * C::STAGE_BYTES + wave * RPI * C::HROWB;
+    char* la = smem + slot * C::STAGE_BYTES + wave_s * RPI * C::HROWB;
     char* lb = la + A_BYTES;
     // DUAL (KH = KW = 1, pad = 0): channel slice cc comes from `in` or from `in2`
     const int c0 = cc * BKE + lchunk * E + hoff / (int)sizeof(T);
@@ -208,6 +238,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       const char* src = w_src[q] ? w_src[q] + w_off : p.zeros;
       glds16(src, lb + q * RSTEP * C::HROWB);
     }
+  };
+  auto stage = [&](int hs, int slot) {
+    if (pure) stage_pure(slot);
+    else stage_general(hs, slot);
   };
 
   // ---- accumulators ---------------------------------------------------------------------

@@ -37,7 +37,7 @@ extern "C" int mhip_init(int device_id, mhip_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return MHIP_EHIP;
   mhip_ctx* ctx = new mhip_ctx();
   ctx->device = device_id;
-  if (hipMalloc(&ctx->zeros, 4096) != hipSuccess || hipMemset(ctx->zeros, 0, 4096) != hipSuccess) {
+  if (hipMalloc(&ctx->zeros, MHIP_ZERO_BYTES) != hipSuccess || hipMemset(ctx->zeros, 0, MHIP_ZERO_BYTES) != hipSuccess) {
     delete ctx;
     return MHIP_ENOMEM;
   }
