@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   // and the bounds of every chunk for every slice (~130 instructions per wave and slice, issued by both waves of a SIMD
   // right after the barrier, when nobody has MFMA work yet).
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const bool pure = !DUAL && !C::KSPLIT && POOL == POOL_NONE && p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 &&
+  const bool pure = !DUAL && POOL == POOL_NONE && p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 &&
                     p.sy == 1 && (size_t)p.Ktot * sizeof(T) + ROWB <= (size_t)MHIP_ZERO_BYTES;
   if (pure) {
 #pragma unroll
@@ -189,18 +189,33 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     for (int q = 0; q < C::WCHUNKS; ++q)
       if (!w_src[q]) w_src[q] = p.zeros + lchunk * 16;
   }
-  auto stage_pure = [&](int slot) {      // called once per slice, in K order
+  auto stage_pure = [&](int slot) {      // called once per (half-)slice, in K order
     char* la = smem + slot * C::STAGE_BYTES + wave_s * RPI * C::HROWB;
     char* lb = la + A_BYTES;
 #pragma unroll
     for (int q = 0; q < C::ACHUNKS; ++q) {
       glds16(a_src[q], la + q * RSTEP * C::HROWB);
-      a_src[q] += ROWB;
+      a_src[q] += C::HROWB;
     }
 #pragma unroll
     for (int q = 0; q < C::WCHUNKS; ++q) {
       glds16(w_src[q], lb + q * RSTEP * C::HROWB);
-      w_src[q] += ROWB;
+      w_src[q] += C::HROWB;
+    }
+  };
+  // one DMA instruction of a (half-)slice: g < ACHUNKS -> A chunk g, else W chunk g - ACHUNKS.  The main loop issues them
+  // BETWEEN groups of MFMAs: a wave that issues its 8 DMA instructions back to back sits in the vector-memory queue
+  // behind the other waves' (64 KiB per slice drain at ~31 B/clk/CU: the second half of the waves measured ~2000 cycles
+  // in `stage` before their first MFMA — profiles/r01/s_loop_phases.txt), and nothing overlaps that wait.
+  auto stage_pure_chunk = [&](int slot, int g) {
+    char* la = smem + slot * C::STAGE_BYTES + wave_s * RPI * C::HROWB;
+    if (g < C::ACHUNKS) {
+      glds16(a_src[g], la + g * RSTEP * C::HROWB);
+      a_src[g] += C::HROWB;
+    } else {
+      const int q = g - C::ACHUNKS;
+      glds16(w_src[q], la + A_BYTES + q * RSTEP * C::HROWB);
+      w_src[q] += C::HROWB;
     }
   };
   auto stage_general = [&](int hs, int slot) {
@@ -276,8 +291,21 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   if (nsteps > 0) stage(0, 0);
   if (D > 1 && nsteps > 1) stage(1, 1);
   if (D > 2 && nsteps > 2) stage(2, 2);
+#ifdef IGEMM_DBG_CLOCK     // measurement aid (rule: the in-kernel clock is d(s_memtime) / d(s_memrealtime) x 100 MHz)
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int slot = 0, fill = D % C::NSTAGE;
+#ifdef IGEMM_DBG_CLOCK
+  unsigned long long dbg_ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DBG_STAMP(k) do { if (it == nsteps / 2) dbg_ph[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DBG_STAMP(k) do { } while (0)
+#endif
   for (int it = 0; it < nsteps; ++it) {
+#ifdef IGEMM_DBG_CLOCK
+    if (it == nsteps / 2 + 1) dbg_ph[8] = __builtin_amdgcn_s_memtime();
+#endif
+    DBG_STAMP(0);
     const int younger = min(D - 1, nsteps - 1 - it);   // (half-)slices issued after the one needed now
     if (C::GL == 6) {
       if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -290,8 +318,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       static_assert(D == 1 || C::GL == 6 || (C::GL == 4 && D == 3), "counted vmcnt table");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    DBG_STAMP(1);
     __builtin_amdgcn_s_barrier();
-    if (it + D < nsteps) stage(it + D, fill);
+    DBG_STAMP(2);
+    const bool feed = it + D < nsteps;
+#ifndef IGEMM_NO_INTERLEAVE
+    const bool interleave = pure && feed;   // plain GEMMs: the next slice's DMA instructions go between this slice's MFMAs
+#else
+    const bool interleave = false;
+#endif
+    if (feed && !interleave) stage(it + D, fill);
+    DBG_STAMP(3);
     const char* sb = smem + slot * C::STAGE_BYTES;
 #pragma unroll
     for (int s = 0; s < (C::KSPLIT ? 1 : 2); ++s) {
@@ -300,21 +337,48 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       for (int t = 0; t < 4; ++t) b[t] = *(const chunk_t*)(sb + (b_off0[t] ^ (s << 6)));
 #pragma unroll
       for (int t = 0; t < MT; ++t) a[t] = *(const chunk_t*)(sb + (a_off0[t] ^ (s << 6)));
+#ifdef IGEMM_DBG_CLOCK
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (s == 0) DBG_STAMP(4); else DBG_STAMP(6);
+#endif
 #ifndef IGEMM_NO_SETPRIO
       __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster between the barriers (cdna guide T5)
 #endif
+      // plain GEMM: one DMA instruction of the next slice in front of every IL_EVERY-th MFMA of the slice (counted over
+      // both k-groups), so that the waves' demand on the vector-memory queue stays near what it drains (~33 cycles per
+      // 1 KiB instruction per CU) and no wave sits in the queue with its MFMAs behind it; the last one is issued early
+      // enough to land under the rest of the slice.  One MFMA sequence for both cases — only the DMA instructions sit
+      // behind a uniform branch.
+#ifndef IGEMM_IL_EVERY
+#define IGEMM_IL_EVERY 4
+#endif
+      constexpr int NM = MT * 4, EVERY = C::KSPLIT ? (NM + C::GL - 1) / C::GL : ((MT == 8) ? IGEMM_IL_EVERY : (2 * NM + C::GL - 1) / C::GL / 2);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int idx = 0; idx < NM; ++idx) {
+        const int gidx = s * NM + idx;                     // position in the slice's MFMA sequence
+        if (gidx % EVERY == 0 && gidx / EVERY < C::GL) {
+          if (interleave) stage_pure_chunk(fill, gidx / EVERY);
+        }
+        Tr<T>::mma(a[idx / 4], b[idx % 4], acc[idx / 4][idx % 4]);
+      }
+      if (s == (C::KSPLIT ? 0 : 1) && interleave) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Tr<T>::mma(a[i], b[j], acc[i][j]);
+        for (int g = ((C::KSPLIT ? 1 : 2) * NM + EVERY - 1) / EVERY; g < C::GL; ++g) stage_pure_chunk(fill, g);   // left-overs
+      }
 #ifndef IGEMM_NO_SETPRIO
       __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef IGEMM_DBG_CLOCK
+      if (s == 0) DBG_STAMP(5); else DBG_STAMP(7);
 #endif
     }
     slot = (slot == C::NSTAGE - 1) ? 0 : slot + 1;
     fill = (fill == C::NSTAGE - 1) ? 0 : fill + 1;
   }
 
+#ifdef IGEMM_DBG_CLOCK
+  const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime(), dbg_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef IGEMM_DBG_NO_EPI    // measurement aid: main loop only
   if (acc[0][0][0] == 123.456f) *(float*)p.out = acc[1][1][1];
   return;
@@ -446,6 +510,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   } else {
     if (gelu) body(N_{}, N_{}, Y{}, Y{}); else if (has_res) body(N_{}, Y{}, N_{}, Y{}); else body(N_{}, N_{}, N_{}, Y{});
   }
+#ifdef IGEMM_DBG_CLOCK     // corrupts 16 output bytes: timing builds only
+  if (blockIdx.x == gridDim.x / 2 && lane == 0) {      // every wave of one workgroup: absolute stamps of the middle slice
+    __builtin_amdgcn_s_sleep(64);
+    unsigned long long* o = (unsigned long long*)p.out;
+    if (wave == 0) { o[0] = dbg_t1 - dbg_t0; o[1] = dbg_r1 - dbg_r0; }
+    for (int k = 0; k < 9; ++k) o[2 + wave * 9 + k] = dbg_ph[k];
+  }
+#endif
 }
 
 template <typename T, int BN_>

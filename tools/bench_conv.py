@@ -82,6 +82,18 @@ def main():
         med, mn = statistics.median(times[name]), min(times[name])
         tot += med
         print(f"{name:34s} median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us  {flops / med / 1e9:7.0f} TFLOP/s (median)")
+        if os.environ.get("IGEMM_DBG_CLOCK"):      # library built with EXTRA=-DIGEMM_DBG_CLOCK: main-loop cycles / 10 ns ticks of one tile
+            torch.cuda.synchronize()
+            raw = out.view(-1).view(torch.uint8)[:8 * 74].cpu().numpy().view("<u8")
+            cyc, ticks = int(raw[0]), int(raw[1])
+            st = raw[2:74].reshape(8, 9).astype("int64")
+            t0 = int(st[:, 0].min())
+            print("    middle K slice, cycles since the first wave's top: top | waited | barrier | staged | reads0 | mfma0 | reads1 | mfma1 | next top")
+            for wv in range(8):
+                print("      wave %d: " % wv + " ".join("%5d" % (int(v) - t0) for v in st[wv]))
+            if ticks:
+                print(f"    main loop of one tile: {cyc} cycles in {ticks * 10} ns -> {cyc / (ticks * 10.0):.2f} GHz, "
+                      f"{cyc / max(1, d.Cin * d.KH * d.KW // (64 if a.precision == 'f16' else 32)):.0f} cycles per K slice")
     print(f"sum of medians {tot * 1e3:.1f} us")
 
 
