@@ -132,7 +132,14 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc_o[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
-  float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+  // Online soft-max with a STALE reference: scores come out of the MFMA already minus the row's reference m (it is the
+  // accumulator's initial value), and m only moves when a tile's maximum exceeds it by more than RESCALE_AT (2^8 in
+  // probability) — then, and on the first tile, O^T and l are rescaled.  On every other tile the per-element subtraction,
+  // the alpha exponentials and the 32 accumulator multiplies disappear from a loop whose VALU work (~800 cycles per tile
+  // and wave) exceeds its MFMA work (512).  O / l at the end is independent of the reference.
+  constexpr float RESCALE_AT = 8.f;
+  float4v negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // -m of this lane's query, broadcast: the MFMA's C operand
+  float lrow[2] = {0.f, 0.f};
 
   // fragment read offsets (row = n within a 16-row tile, logical slot = g (+4 for the second k step))
   int foff[4];
@@ -158,8 +165,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
     float4v s[4][2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      s[kt][0] = (float4v){0.f, 0.f, 0.f, 0.f};
-      s[kt][1] = (float4v){0.f, 0.f, 0.f, 0.f};
+      s[kt][0] = negm[0];
+      s[kt][1] = negm[1];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const half8 a = *(const half8*)(sk + (foff[kt] ^ (ks << 6)));
@@ -179,29 +186,46 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
     }
     // ---- online softmax (base 2; the log2 e factor lives in the query scale) -------------------------------
     half8 pb[2][2];
+    float tmax[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float mx = mrow[qt];
+      float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mx);   // first tile: exp2(-inf) = 0
-      mrow[qt] = mx;
+      tmax[qt] = mx;                       // the tile's maximum relative to the reference
+    }
+    const bool move = t == 0 || tmax[0] > RESCALE_AT || tmax[1] > RESCALE_AT;
+    if (__builtin_amdgcn_ballot_w64(move) != 0) {      // wave-uniform: some query of this wave moves its reference
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        // first tile: the reference becomes the tile maximum whatever it is; later: a query moves only on ITS OWN excess
+        // (d = 0 leaves it bit-for-bit alone: alpha = 1, s - 0), so its arithmetic never depends on its wave's neighbours
+        const float d = t == 0 ? tmax[qt] : (tmax[qt] > RESCALE_AT ? tmax[qt] : 0.f);
+        const float alpha = t == 0 ? 0.f : __builtin_amdgcn_exp2f(-d);
+        negm[qt] -= (float4v){d, d, d, d};
+        lrow[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt][qt] -= (float4v){d, d, d, d};
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
       float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[kt][qt][r] - mx);
+          const float e = __builtin_amdgcn_exp2f(s[kt][qt][r]);
           sum += e;
           pb[qt][kt >> 1][(kt & 1) * 4 + r] = (_Float16)e;
         }
-      lrow[qt] = lrow[qt] * alpha + sum;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
+      lrow[qt] += sum;
     }
     // ---- O^T += V^T P^T ----------------------------------------------------------------------------------------
 #pragma unroll
