@@ -112,7 +112,10 @@ constexpr int DA_WAVES = 4;   // (MAXQ, MAXK) instantiations: cross-attention (4
 
 // One WAVE per (group, head): a 16-byte chunk of a key row per lane, so a wave-instruction reads whole 128-byte (f16) /
 // 256-byte (fp32) head rows of 8 / 4 consecutive keys — every K and V byte is fetched once, fully coalesced.
-template <typename T, int DA_MAXQ, int DA_MAXK>
+// ANC (compile time): keys are addressed through the ancestry table (self-attention) or directly (cross-attention).  As a
+// run-time test inside key_row() the table load sat behind a uniform branch, and the compiler then waits for ALL
+// outstanding loads (vmcnt(0)) at every join — the four K / V loads of an iteration went out one at a time.
+template <typename T, int DA_MAXQ, int DA_MAXK, bool ANC>
 __global__ __launch_bounds__(64 * DA_WAVES) void decode_attn_kernel(DecAttnArgs p, int heads, int tasks) {
   constexpr int EPC = 16 / (int)sizeof(T);        // elements per chunk: 8 / 4
   constexpr int CPR = 64 / EPC;                   // chunks per head row: 8 / 16
@@ -124,8 +127,17 @@ __global__ __launch_bounds__(64 * DA_WAVES) void decode_attn_kernel(DecAttnArgs 
   const int h = live ? task % heads : 0, grp = live ? task / heads : 0;
   const int row0 = grp * p.nq;
   const int c = lane % CPR, ks = lane / CPR;
+  // self-attention: the hypothesis' ancestry row (slot of every past step) goes to LDS once, so that key addresses depend on
+  // an LDS read instead of a global load in front of every K / V load
+  __shared__ int sanc[ANC ? DA_WAVES : 1][ANC ? DA_MAXK : 1];
+  if constexpr (ANC) {
+    if (live)
+      for (int s = lane; s < p.n_keys; s += 64) sanc[wave][s] = p.anc[(size_t)row0 * p.anc_ld + s];
+    __syncthreads();
+  }
   auto key_row = [&](int s) -> size_t {
-    return p.anc ? ((size_t)s * p.slots + p.anc[(size_t)row0 * p.anc_ld + s]) : ((size_t)grp * p.kv_rows + s);
+    if constexpr (ANC) return (size_t)s * p.slots + sanc[wave][s];
+    else return (size_t)grp * p.kv_rows + s;
   };
   float q[DA_MAXQ][EPC];
 #pragma unroll
@@ -413,10 +425,12 @@ int mhip_launch_decode_attention(mhip_ctx* ctx, int precision, const DecAttnDesc
   a.kv_rows = d.kv_rows; a.ldq = d.ldq; a.ldk = d.ldk; a.ldo = d.ldo; a.n_keys = d.n_keys; a.nq = d.nq;
   const int tasks = d.heads * d.groups;
   dim3 grid((tasks + DA_WAVES - 1) / DA_WAVES), block(64 * DA_WAVES);
-#define DA_LAUNCH(T, Q, K) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL((decode_attn_kernel<T, Q, K>), grid, block, 0, ctx->stream, a, d.heads, tasks))
+#define DA_LAUNCH1(T, Q, K, A) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL((decode_attn_kernel<T, Q, K, A>), grid, block, 0, ctx->stream, a, d.heads, tasks))
+#define DA_LAUNCH(T, Q, K) do { if (d.anc) DA_LAUNCH1(T, Q, K, true); else DA_LAUNCH1(T, Q, K, false); } while (0)
   if (precision == MHIP_PREC_F16) { if (small) DA_LAUNCH(_Float16, 1, 256); else DA_LAUNCH(_Float16, 4, 640); }
   else { if (small) DA_LAUNCH(float, 1, 256); else DA_LAUNCH(float, 4, 640); }
 #undef DA_LAUNCH
+#undef DA_LAUNCH1
   CHECK_LAUNCH(ctx, "decode_attention");
   return 0;
 }
