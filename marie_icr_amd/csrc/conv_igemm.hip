@@ -421,6 +421,33 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       char* wst = wst0 + (i & 1) * (16 * SPW);
+      // The residual values of this row-tile are requested before its LDS transpose: read next to the store, every one of
+      // the 32 (fp32) / 16 (f16) chunks of a wave paid a full load latency plus the drain of the previous store (vmcnt
+      // counts both), one after the other.  A chunk is read and written by the same lane only, so in-place residuals
+      // (res == out) stay correct.
+      constexpr int NRES32 = RT * 16 / 64, NRES16 = (RT * 8 + 63) / 64;
+      float4v rres32[RES && OUT32 && VEC ? NRES32 : 1];
+      half8 rres16[RES && !OUT32 && VEC ? NRES16 : 1];
+      if (RES && VEC) {
+        const int qb0 = (m0 + wr * (MT * 16) + i * 16) / PF;
+        if (OUT32) {
+#pragma unroll
+          for (int t = 0; t < NRES32; ++t) {
+            const int cidx = t * 64 + lane, row = cidx >> 4, ch = cidx & 15;
+            const int q = qb0 + row, n = n0 + wc * 64 + ch * 4;
+            rres32[t] = (float4v){0.f, 0.f, 0.f, 0.f};
+            if (q < Mq && n < p.N) rres32[t] = *(const float4v*)(p.res + (size_t)res_row(q) * grow + (size_t)n * oe);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NRES16; ++t) {
+            const int cidx = t * 64 + lane, row = cidx >> 3, ch = cidx & 7;
+            const int q = qb0 + row, n = n0 + wc * 64 + ch * 8;
+            rres16[t] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (row < RT && q < Mq && n < p.N) rres16[t] = *(const half8*)(p.res + (size_t)res_row(q) * grow + (size_t)n * 2);
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int lc = j * 16 + frow;
@@ -441,31 +468,44 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       __builtin_amdgcn_wave_barrier();
       const int qbase = (m0 + wr * (MT * 16) + i * 16) / PF;
       if (VEC && !OUT32) {
-        // f16 out: 8 columns per lane = one 16-byte store; 8 lanes cover a row's 64 columns (128 contiguous bytes)
+        // f16 out: 8 columns per lane = one 16-byte store; 8 lanes cover a row's 64 columns (128 contiguous bytes).
+        // All chunks of the row-tile are produced first and stored together: a store issued between two LDS reads that
+        // reuse its data registers makes the compiler drain the store (vmcnt(0)) before every read.
+        half8 ov[NRES16];
+        size_t ooff[NRES16];
+        bool ook[NRES16];
 #pragma unroll
-        for (int t = 0; t < (RT * 8 + 63) / 64; ++t) {
+        for (int t = 0; t < NRES16; ++t) {
           const int cidx = t * 64 + lane;
           const int row = cidx >> 3, ch = cidx & 7;
           const int q = qbase + row, n = n0 + wc * 64 + ch * 8;
-          if (row < RT && q < Mq && n < p.N) {
+          ook[t] = row < RT && q < Mq && n < p.N;
+          ooff[t] = 0;
+          if (ook[t]) {
             const float4v a0 = *(const float4v*)(wst + row * SPW + ch * 32), a1 = *(const float4v*)(wst + row * SPW + ch * 32 + 16);
             float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             if (GELU)
 #pragma unroll
               for (int k = 0; k < 8; ++k) f[k] = gelu_erf(f[k]);
-            const size_t off = (size_t)out_row(q) * grow + (size_t)n * 2;
+            ooff[t] = (size_t)out_row(q) * grow + (size_t)n * 2;
             if (RES) {
-              const half8 r8 = *(const half8*)(p.res + (size_t)res_row(q) * grow + (size_t)n * 2);
+              const half8 r8 = rres16[t];
 #pragma unroll
               for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] + (float)r8[k], lo2);
             }
-            half8 o;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = (_Float16)f[k];
-            *(half8*)(p.out + off) = o;
+            for (int k = 0; k < 8; ++k) ov[t][k] = (_Float16)f[k];
           }
         }
+#pragma unroll
+        for (int t = 0; t < NRES16; ++t)
+          if (ook[t]) *(half8*)(p.out + ooff[t]) = ov[t];
       } else {
+        float4v ov32[NRES32];
+        size_t ooff32[NRES32];
+        bool ook32[NRES32];
+#pragma unroll
+        for (int t = 0; t < NRES32; ++t) ook32[t] = false;
 #pragma unroll
         for (int t = 0; t < RT * 16 / 64; ++t) {
           const int cidx = t * 64 + lane;
@@ -478,13 +518,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
               for (int k = 0; k < 4; ++k) a[k] = gelu_erf(a[k]);
             const size_t off = (size_t)out_row(q) * grow + (size_t)n * oe;
             const size_t roff = (size_t)res_row(q) * grow + (size_t)n * oe;
-            if (VEC) {     // fp32 out
+            if (VEC) {     // fp32 out: kept in registers, stored after the loop (see the f16 branch)
               if (RES) {
-                a += *(const float4v*)(p.res + roff);
+                a += rres32[t];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a[k] = fmaxf(a[k], lo2);
               }
-              *(float4v*)(p.out + off) = a;
+              ov32[t] = a;
+              ooff32[t] = off;
+              ook32[t] = true;
             } else {       // ragged N (e.g. the 95-class prediction layer): element-wise, everything decided at run time
 #pragma unroll
               for (int k = 0; k < 4; ++k)
@@ -496,6 +538,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
                 }
             }
           }
+        }
+        if (VEC) {
+#pragma unroll
+          for (int t = 0; t < NRES32; ++t)
+            if (ook32[t]) *(float4v*)(p.out + ooff32[t]) = ov32[t];
         }
       }
     }
