@@ -163,6 +163,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
 
     // ---- S^T = K Q^T ------------------------------------------------------------------------------------
     float4v s[4][2];
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       s[kt][0] = negm[0];
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
         s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qreg[1][ks], s[kt][1], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if ((t + 1) * AT_KT > p.n_keys) {   // keys past the end of the image (padding rows)
       const int kbase = t * AT_KT;
 #pragma unroll
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
       lrow[qt] += sum;
     }
     // ---- O^T += V^T P^T ----------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
         acc_o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[0][c], acc_o[dt][0], 0, 0, 0);
         acc_o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[1][c], acc_o[dt][1], 0, 0, 0);
       }
+    __builtin_amdgcn_s_setprio(0);
     slot = slot == AT_NSTAGE - 1 ? 0 : slot + 1;
     fill = fill == AT_NSTAGE - 1 ? 0 : fill + 1;
   }
