@@ -481,6 +481,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
           const int q = qbase + row, n = n0 + wc * 64 + ch * 8;
           ook[t] = row < RT && q < Mq && n < p.N;
           ooff[t] = 0;
+          ov[t] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
           if (ook[t]) {
             const float4v a0 = *(const float4v*)(wst + row * SPW + ch * 32), a1 = *(const float4v*)(wst + row * SPW + ch * 32 + 16);
             float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -497,15 +498,24 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
             for (int k = 0; k < 8; ++k) ov[t][k] = (_Float16)f[k];
           }
         }
+        // every store of the group gets its own address and data registers, fixed BEFORE the first one is issued: with the
+        // address formed next to each store the same register pair is recycled, and rewriting a register an in-flight
+        // store still reads costs a full vmcnt(0) between consecutive stores
+        unsigned long long dst16[NRES16];
+#pragma unroll
+        for (int t = 0; t < NRES16; ++t) {
+          dst16[t] = (unsigned long long)(p.out + ooff[t]);
+          asm volatile("" : "+v"(dst16[t]), "+v"(ov[t]));
+        }
 #pragma unroll
         for (int t = 0; t < NRES16; ++t)
-          if (ook[t]) *(half8*)(p.out + ooff[t]) = ov[t];
+          if (ook[t]) *(__attribute__((address_space(1))) half8*)dst16[t] = ov[t];   // global, not flat: the asm hides the provenance
       } else {
         float4v ov32[NRES32];
         size_t ooff32[NRES32];
         bool ook32[NRES32];
 #pragma unroll
-        for (int t = 0; t < NRES32; ++t) ook32[t] = false;
+        for (int t = 0; t < NRES32; ++t) { ook32[t] = false; ooff32[t] = 0; ov32[t] = (float4v){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int t = 0; t < RT * 16 / 64; ++t) {
           const int cidx = t * 64 + lane;
@@ -540,9 +550,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
           }
         }
         if (VEC) {
+          unsigned long long dst32[NRES32];
+#pragma unroll
+          for (int t = 0; t < NRES32; ++t) {
+            dst32[t] = (unsigned long long)(p.out + (ook32[t] ? ooff32[t] : 0));
+            asm volatile("" : "+v"(dst32[t]), "+v"(ov32[t]));
+          }
 #pragma unroll
           for (int t = 0; t < NRES32; ++t)
-            if (ook32[t]) *(float4v*)(p.out + ooff32[t]) = ov32[t];
+            if (ook32[t]) *(__attribute__((address_space(1))) float4v*)dst32[t] = ov32[t];
         }
       }
     }
