@@ -150,9 +150,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   const char* a_src[C::ACHUNKS];
   int a_y[C::ACHUNKS], a_x[C::ACHUNKS];
   const char* w_src[C::WCHUNKS];
+  // plain GEMM (see `stage_pure` below): pixel index = row index, no row decoding (three integer divisions per chunk)
+  const bool pure = !DUAL && !C::KSPLIT && POOL == POOL_NONE && p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 &&
+                    p.sy == 1 && (size_t)p.Ktot * sizeof(T) + ROWB <= (size_t)MHIP_ZERO_BYTES;
 #pragma unroll
   for (int q = 0; q < C::ACHUNKS; ++q) {
     int m = m0 + q * RSTEP + srow;
+    if (pure) {
+      a_y[q] = a_x[q] = 0;
+      a_src[q] = p.in + ((size_t)m * p.Cin + (size_t)lchunk * E) * sizeof(T);   // rows beyond M are redirected below
+      continue;
+    }
     int b = 0, y = -100000, x = -100000;  // invalid rows fail every bounds test
     if (m < p.M) decode_row<POOL>(p, m, b, y, x);
     a_y[q] = y;
@@ -179,8 +187,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   // and the bounds of every chunk for every slice (~130 instructions per wave and slice, issued by both waves of a SIMD
   // right after the barrier, when nobody has MFMA work yet).
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const bool pure = !DUAL && POOL == POOL_NONE && p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 &&
-                    p.sy == 1 && (size_t)p.Ktot * sizeof(T) + ROWB <= (size_t)MHIP_ZERO_BYTES;
   if (pure) {
 #pragma unroll
     for (int q = 0; q < C::ACHUNKS; ++q)
