@@ -404,7 +404,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   const float lo = (p.relu == ACT_RELU && !p.res) ? 0.f : -INFINITY;   // ReLU without a residual: here, branch-free
   const float lo2 = (p.relu == ACT_RELU && p.res) ? 0.f : -INFINITY;   // with a residual: after the add
   const bool gelu = p.relu == ACT_GELU;
-  const bool vec = (grow & 15) == 0 && (p.N & 7) == 0;   // whole, 16-byte aligned column groups in every row
+  // whole, 16-byte aligned column groups in every row — or a row pitch that leaves room for the last, partly filled group
+  // (the logits GEMM: N = 50 265 columns in rows of 50 272): the pad columns receive zeros (weight rows beyond N read the
+  // zero page) instead of sending the whole GEMM down the element-wise path (measured 20 us of epilogue per tile there
+  // against 4 us)
+  const bool vec = (grow & 15) == 0 && ((p.N & 7) == 0 || (p.ldc >= ((p.N + 7) & ~7)));
   float sc4[4], bi4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
