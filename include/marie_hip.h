@@ -291,6 +291,11 @@ int mhip_dit_detect_host(mhip_dit* m, const uint8_t* pages_host, int B, int h, i
 int mhip_dit_debug_host(mhip_dit* m, const uint8_t* page_host, int h, int w, float* boxes_host, float* scores_host,
                         int* count_host, float* p2, float* p3, float* p4, float* p5, float* p6, float* prop_boxes,
                         float* prop_scores, int* prop_count);
+/* same plus the inputs of the two discrete stages as this run computed them: fpn5[l] as above, rpn_head5[l] fp32
+ * [H*W][16] for p2..p6, box_head fp32 [1000][8] (rows past *prop_count undefined); any pointer may be NULL             */
+int mhip_dit_debug_taps_host(mhip_dit* m, const uint8_t* page_host, int h, int w, float* boxes_host, float* scores_host,
+                             int* count_host, float* const* fpn5, float* const* rpn_head5, float* prop_boxes,
+                             float* prop_scores, int* prop_count, float* box_head);
 /* The detectron2 stages of the detector on caller-supplied host inputs (each also used by the parity tests):
  * RPN.predict_proposals for one image — heads_host[l] fp32 [H[l]*W[l]][16] (3 objectness logits, 3 x 4 deltas, 1 pad) for
  * p2..p6 -> up to 1000 proposals xyxy + logits, score-ordered;                                                          */

@@ -79,6 +79,7 @@ _SIGNATURES = (
     ("mhip_dit_detect", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     ("mhip_dit_detect_host", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     ("mhip_dit_debug_host", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mhip_dit_debug_taps_host", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mhip_rpn_proposals_host", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp]),
     ("mhip_roi_align_host", _i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     ("mhip_det_final_host", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, _i, _vp, _vp, _vp]),

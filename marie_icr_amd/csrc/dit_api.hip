@@ -275,6 +275,8 @@ struct DitDebug {
   float* prop_boxes = nullptr;   // host [1000][4]
   float* prop_scores = nullptr;  // host [1000]
   int* prop_count = nullptr;
+  float* rpn_head[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // host fp32 [H*W][16] per level (3 logits, 12 deltas, pad)
+  float* box_head = nullptr;     // host fp32 [1000][8] (2 class scores, 4 deltas, 2 pad), rows past prop_count undefined
 };
 
 static int dit_run(mhip_dit* m, const uint8_t* const* pages_dev, int B, int h, int w, float* boxes_host, float* scores_host,
@@ -379,6 +381,10 @@ static int dit_run(mhip_dit* m, const uint8_t* const* pages_dev, int B, int h, i
         MHIP_HIP(ctx, hipMemcpyAsync(dbg->fpn[l], stage, (size_t)rows * FPN_C * 4, hipMemcpyDeviceToHost, ctx->stream));
         MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
       }
+    for (int l = 0; l < 5; ++l)
+      if (dbg->rpn_head[l])
+        MHIP_HIP(ctx, hipMemcpyAsync(dbg->rpn_head[l], rd.head[l], (size_t)g.lh[l] * g.lw[l] * 64, hipMemcpyDeviceToHost, ctx->stream));
+    if (dbg->box_head) MHIP_HIP(ctx, hipMemcpyAsync(dbg->box_head, hd, (size_t)MAX_ROIS * 32, hipMemcpyDeviceToHost, ctx->stream));
     if (dbg->prop_boxes) MHIP_HIP(ctx, hipMemcpyAsync(dbg->prop_boxes, rd.out_boxes, MAX_ROIS * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (dbg->prop_scores) MHIP_HIP(ctx, hipMemcpyAsync(dbg->prop_scores, rd.out_scores, MAX_ROIS * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (dbg->prop_count) MHIP_HIP(ctx, hipMemcpyAsync(dbg->prop_count, rd.out_counts, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -430,6 +436,34 @@ extern "C" int mhip_dit_debug_host(mhip_dit* m, const uint8_t* page_host, int h,
     DitDebug d;
     d.fpn[0] = p2; d.fpn[1] = p3; d.fpn[2] = p4; d.fpn[3] = p5; d.fpn[4] = p6;
     d.prop_boxes = prop_boxes; d.prop_scores = prop_scores; d.prop_count = prop_count;
+    const uint8_t* ptr = dev;
+    rc = dit_run(m, &ptr, 1, h, w, boxes_host, scores_host, count_host, &d);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dev);
+  return rc;
+}
+
+// same, plus the inputs of the two discrete stages (RPN selection, FastRCNN inference) as this run computed them: the
+// parity tests replay the oracle's discrete stages on them
+extern "C" int mhip_dit_debug_taps_host(mhip_dit* m, const uint8_t* page_host, int h, int w, float* boxes_host,
+                                        float* scores_host, int* count_host, float* const* fpn5, float* const* rpn_head5,
+                                        float* prop_boxes, float* prop_scores, int* prop_count, float* box_head) {
+  if (!m || !page_host || !boxes_host || !count_host) return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  uint8_t* dev = nullptr;
+  const size_t pb = (size_t)h * w * 3;
+  MHIP_HIP(ctx, hipMalloc((void**)&dev, pb));
+  hipError_t e = hipMemcpy(dev, page_host, pb, hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? MHIP_OK : mhip_fail(ctx, MHIP_EHIP, "page upload: %s", hipGetErrorString(e));
+  if (!rc) {
+    DitDebug d;
+    for (int l = 0; l < 5; ++l) {
+      if (fpn5) d.fpn[l] = fpn5[l];
+      if (rpn_head5) d.rpn_head[l] = rpn_head5[l];
+    }
+    d.prop_boxes = prop_boxes; d.prop_scores = prop_scores; d.prop_count = prop_count; d.box_head = box_head;
     const uint8_t* ptr = dev;
     rc = dit_run(m, &ptr, 1, h, w, boxes_host, scores_host, count_host, &d);
   }

@@ -87,20 +87,27 @@ class DitModel:
         return self._unpack(boxes, scores, counts)
 
     def debug_host(self, page_bgr: np.ndarray):
+        """One page plus what the parity tests look at: FPN maps, the RPN head outputs and the box-head outputs (the inputs
+        of the two discrete stages as this run computed them), proposals and detections."""
         page = np.ascontiguousarray(page_bgr, np.uint8)
         h, w, _ = page.shape
         nh, nw, H32, W32 = self.resized_shape(h, w)
         sizes = [(H32 >> (2 + l), W32 >> (2 + l)) for l in range(4)]
         sizes.append(((sizes[3][0] + 1) // 2, (sizes[3][1] + 1) // 2))
         fpn = [np.empty((s[0], s[1], 256), np.float32) for s in sizes]
+        rpn = [np.empty((s[0] * s[1], 16), np.float32) for s in sizes]
         boxes, scores = np.empty((MAX_ROIS, 4), np.float32), np.empty((MAX_ROIS,), np.float32)
         pb, ps = np.empty((MAX_ROIS, 4), np.float32), np.empty((MAX_ROIS,), np.float32)
+        head = np.empty((MAX_ROIS, 8), np.float32)
         n, pn = C.c_int(0), C.c_int(0)
-        check(self.ctx.h, self.lib.mhip_dit_debug_host(self.h, _vp(page), h, w, _vp(boxes), _vp(scores), C.byref(n),
-                                                       *[_vp(f) for f in fpn], _vp(pb), _vp(ps), C.byref(pn)),
-              "mhip_dit_debug_host")
+        fp = (C.c_void_p * 5)(*[f.ctypes.data for f in fpn])
+        rp = (C.c_void_p * 5)(*[r.ctypes.data for r in rpn])
+        check(self.ctx.h, self.lib.mhip_dit_debug_taps_host(self.h, _vp(page), h, w, _vp(boxes), _vp(scores), C.byref(n), fp, rp,
+                                                            _vp(pb), _vp(ps), C.byref(pn), _vp(head)),
+              "mhip_dit_debug_taps_host")
         return {"boxes": boxes[: n.value], "scores": scores[: n.value], "fpn": fpn, "proposals": pb[: pn.value],
-                "proposal_scores": ps[: pn.value], "resized_hw": (nh, nw)}
+                "proposal_scores": ps[: pn.value], "resized_hw": (nh, nw), "sizes": sizes,
+                "rpn_heads": [r[:, :15].copy() for r in rpn], "head": head[: pn.value, :6].copy()}
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:

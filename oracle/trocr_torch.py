@@ -93,6 +93,29 @@ class TorchTrocrOracle:
         return F.linear(x, w)
 
     @torch.no_grad()
+    def score_tokens(self, crops_rgb_u8: np.ndarray, token_lists) -> List[float]:
+        """Teacher-forced score of a given hypothesis per crop (tokens incl. the final eos): sum of the step log-probabilities
+        / length — the quantity ``generate`` ranks finished hypotheses by.  Used to show that a hypothesis chosen by a
+        reduced-precision run is a near-tie of the oracle's best."""
+        st = self.st
+        enc = self.encode(crops_rgb_u8)
+        out = []
+        for i, toks in enumerate(token_lists):
+            cross = []
+            for l in range(self.layers):
+                p = f"decoder.layers.{l}.encoder_attn."
+                cross.append((F.linear(enc[i:i + 1], st[p + "k_proj.weight"], st[p + "k_proj.bias"]),
+                              F.linear(enc[i:i + 1], st[p + "v_proj.weight"], st[p + "v_proj.bias"])))
+            hist = [None] * self.layers
+            prev, total = self.eos, 0.0
+            for step, t in enumerate(toks):
+                logits = self.decoder_step(torch.tensor([prev]), step, hist, cross)
+                total += float(F.log_softmax(logits.float(), dim=-1)[0, int(t)])
+                prev = int(t)
+            out.append(total / max(len(toks), 1))
+        return out
+
+    @torch.no_grad()
     def generate(self, crops_rgb_u8: np.ndarray, want_step0: bool = False):
         """Returns per crop (tokens incl. eos, normalised score) of the best hypothesis."""
         st = self.st
