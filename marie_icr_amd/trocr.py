@@ -7,8 +7,8 @@ libmarie_hip.so; this file turns token ids into text: fairseq ``Dictionary`` sym
 (marie/models/unilm/trocr/bpe.py:59-67; ``get_text`` :142-180).
 
 The dictionary (``gpt2_with_mask.dict.txt``) and GPT-2's ``encoder.json`` are assets the reference downloads at run time;
-they are not in its tree.  Pass their paths (``dict_path``, ``encoder_json``); without them the processor still runs and
-returns the space-joined token ids as text.
+they are not in its tree.  Pass their paths (``dict_path``, ``encoder_json``); without either the processor still runs and
+returns the space-joined token ids as text (``encoder_json`` without ``dict_path`` is refused).
 """
 from __future__ import annotations
 
@@ -106,21 +106,32 @@ class TrocrModel:
 
 
 # ---------------------------------------------------------------------------------------------------- text side
-def load_fairseq_dictionary(path: str) -> List[str]:
-    """fairseq ``Dictionary.load``: <s>, <pad>, </s>, <unk>, then one ``symbol count`` line each, then ``madeupwordNNNN``
-    fillers up to a multiple of 8."""
+def load_fairseq_dictionary(path: str, pad_to_multiple: int = 1) -> List[str]:
+    """fairseq ``Dictionary.load`` (``add_from_file``) as the reference's task calls it
+    (marie/models/unilm/trocr/task.py:86-101): ``<s>``, ``<pad>``, ``</s>``, ``<unk>``, then one symbol per
+    ``<symbol> <count>[ #fairseq:overwrite]`` line.  A repeated symbol is an error unless its line carries the overwrite flag,
+    in which case it gets a NEW index (the earlier one keeps its slot).  ``Dictionary.load`` does not pad: the 50 265 entries
+    of ``gpt2_with_mask.dict.txt`` are 4 specials + 50 260 lines (its own ``madeupword0000..2`` among them) + ``<mask>``.
+    ``pad_to_multiple`` > 1 appends fairseq's ``madeupwordNNNN`` fillers (``Dictionary.pad_to_multiple_``, used by
+    ``finalize`` at preprocessing time, not by ``load``)."""
     symbols = ["<s>", "<pad>", "</s>", "<unk>"]
+    seen = set(symbols)
     with open(path, "r", encoding="utf-8") as f:
-        for line in f:
-            line = line.rstrip("\n")
-            if not line:
-                continue
-            sym = line.rsplit(" ", 1)[0]
-            if sym.endswith(" #fairseq:overwrite"):
-                sym = sym[: -len(" #fairseq:overwrite")]
-            symbols.append(sym)
+        for raw in f:
+            try:
+                line, field = raw.rstrip().rsplit(" ", 1)
+                overwrite = field == "#fairseq:overwrite"
+                if overwrite:
+                    line, field = line.rsplit(" ", 1)
+                int(field)
+            except ValueError:
+                raise ValueError(f"Incorrect dictionary format, expected '<token> <cnt> [flags]': \"{raw}\"")
+            if line in seen and not overwrite:
+                raise RuntimeError(f"Duplicate word found when loading Dictionary: '{line}'")
+            seen.add(line)
+            symbols.append(line)
     i = 0
-    while len(symbols) % 8 != 0:
+    while pad_to_multiple > 1 and len(symbols) % pad_to_multiple != 0:
         symbols.append(f"madeupword{i:04d}")
         i += 1
     return symbols
@@ -188,6 +199,9 @@ class TrOcrProcessor(OcrProcessor):
             ck = torch.load(model_name_or_path, map_location="cpu", weights_only=True)
             sd = ck.get("model", ck)
             state = {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}
+        if encoder_json and not dict_path:
+            # the dictionary's symbols ARE the GPT-2 BPE ids; decoding dictionary indices as BPE ids would be silently wrong
+            raise ValueError("encoder_json needs dict_path: GPT-2 BPE ids are the fairseq dictionary's symbols, not its indices")
         self.symbols = load_fairseq_dictionary(dict_path) if dict_path else None
         if self.symbols is not None and len(self.symbols) != cfg.vocab:
             raise ValueError(f"dictionary has {len(self.symbols)} symbols, the model expects {cfg.vocab}")

@@ -8,7 +8,9 @@ marie/models/unilm/trocr/generator.py:127-362.  The oracle's detectron2 / fairse
 Bars (written next to each assertion):
   fp32  FPN maps and RPN-head outputs within 2e-3; discrete stages replayed on identical inputs give identical sets (boxes
         within 2e-3 px, scores exact / 1e-6); end to end every box the interval analysis (oracle/dit_trace.py) marks KEPT has
-        a partner at IoU >= 0.999 and every extra / missing box is a proven near-tie; TrOCR tokens exact, score within 1e-3.
+        a partner at IoU >= 0.999 (boxes of a few pixels, whose IoU moves by 0.3 % under a 0.004 px shift: every coordinate
+        within the measured error, < 0.01 px) and every extra / missing box is a proven near-tie; TrOCR tokens exact, score
+        within 1e-3.  Measured (profiles/r02/a_fullsize_parity.json): 911 / 911 boxes, 0 unstable, max |d coordinate| 0.004 px.
   f16   (the bench dtype) maps within 3 % of range; box-set match fractions reported and bounded; TrOCR hypotheses equal or a
         near-tie under the oracle's own scoring (teacher-forced score within 0.02 of the oracle's best).
 Numbers are written to gpurun_out/fullsize_parity.json when that directory exists."""
@@ -149,7 +151,7 @@ def test_dit_base_fp32_full_page(ctx, page, dit_case):
                            (10.0, 10.0, 5.0, 5.0))
     ep = 1.5 * float(np.abs(pr_o - pr_g).max())
     eb2 = 1.5 * float((bx_o - bx_g).abs().max())
-    assert ep <= 2e-3 and eb2 <= 5e-2, (ep, eb2)
+    assert ep <= 2e-3 and eb2 * PAGE_H / nh <= 1e-2, (ep, eb2)     # page-coordinate error of a detection below 0.01 px
     cands = tr.final_intervals(head_all, props["boxes"], props["state"], (nh, nw), (PAGE_H, PAGE_W), ep, eb2)
     chk_strict = tr.check_against(cands, out["boxes"])                     # IoU >= 0.999 only
     chk = tr.check_against(cands, out["boxes"], coord_tol=eb2 * PAGE_H / nh)  # or every coordinate within the measured error
