@@ -124,13 +124,19 @@ class BoxProcessorUlimDit:
               "mhip_blackout_bboxes")
         return bool(changed.value)
 
-    # -- page segmentation ------------------------------------------------------------------------------------------
-    def psm_sparse_step(self, page_dev, shape, adj_x: int, adj_y: int):
-        """reference: ulim_dit_box_processor.py:424-497.  ``page_dev``: CUDA uint8 tensor (h, w, 3) BGR."""
+    def _detect(self, page_dev, shape):
+        """One detector forward on a device page -> (boxes xyxy fp32 page coordinates, scores).  The one call the parity tests
+        swap (oracle detector under this class's control flow, and the other way round)."""
         import torch
 
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         (boxes, scores), = self.model.detect_device([page_dev.data_ptr()], shape[0], shape[1])
+        return boxes, scores
+
+    # -- page segmentation ------------------------------------------------------------------------------------------
+    def psm_sparse_step(self, page_dev, shape, adj_x: int, adj_y: int):
+        """reference: ulim_dit_box_processor.py:424-497.  ``page_dev``: CUDA uint8 tensor (h, w, 3) BGR."""
+        boxes, scores = self._detect(page_dev, shape)
         if len(boxes) == 0:
             return [], [], []
         bboxes = boxes

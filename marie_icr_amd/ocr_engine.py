@@ -224,12 +224,14 @@ class _MemoBoxProcessor:
         return self._memo[k][1]
 
 
-def vote_words(candidates: List[Dict], min_vote_count: int = 2, by_confidence: Optional[Dict] = None) -> Dict:
+def vote_words(candidates: List[Dict], min_vote_count: int = 2, by_confidence: Optional[Dict] = None,
+               first_greater: bool = False) -> Dict:
     """Pick one word among the recognizers' candidates for the same box (all carry the same ``id``).
     reference: VotingOcrEngine.get_words_by_vote_by_selector / voting_evaluator, marie/ocr/voting_ocr_engine.py:186-254,
     420-466: the largest group of identical texts wins if it has at least ``min_vote_count`` members (equal sizes: larger
     confidence sum; the first such group keeps ties); otherwise the default recognizer's word (the first candidate), unless
-    the per-id best-confidence word beats it."""
+    a more confident candidate exists — page mode takes the MOST confident one (:458-466 scans the per-id maxima), region mode
+    the FIRST candidate, in recognizer order, that beats the default (:239-247 scans the candidates and breaks)."""
     groups: Dict[str, List[Dict]] = {}
     for w in candidates:
         groups.setdefault(w["text"], []).append(w)
@@ -247,7 +249,10 @@ def vote_words(candidates: List[Dict], min_vote_count: int = 2, by_confidence: O
         return chosen
     chosen = candidates[0]
     chosen["strategy"] = {"type": "default"}
-    top = by_confidence if by_confidence is not None else max(candidates, key=lambda w: w["confidence"])
+    if first_greater:
+        top = next((w for w in candidates if w["confidence"] > chosen["confidence"]), None)
+    else:
+        top = by_confidence if by_confidence is not None else max(candidates, key=lambda w: w["confidence"])
     if top is not None and top["confidence"] > chosen["confidence"]:
         chosen = top
         chosen["strategy"] = {"type": "confidence", "confidence": top["confidence"]}
@@ -284,7 +289,7 @@ def voting_evaluator(aggregated_results: "OrderedDict[str, Any]", default_result
             for c in cands:                     # first strictly-larger confidence wins, as in the reference's scan
                 if c["confidence"] > top["confidence"]:
                     top = c
-            voted[uid].append(vote_words(cands, 2, top))
+            voted[uid].append(vote_words(cands, 2, top, first_greater=has_regions))
     out = deepcopy(default_results)
     if not has_regions:
         for idx, page in enumerate(out):

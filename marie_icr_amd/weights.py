@@ -524,3 +524,35 @@ def make_ocr_result(seed: int, width: int, height: int, n_lines: int = 12, page:
     return {"meta": {"imageSize": {"width": int(width), "height": int(height)}, "page": int(page), "lang": "en",
                      "format": "xywh"},
             "words": [words[int(i)] for i in order], "lines": lines}
+
+
+def make_voting_case(seed: int, regions: bool):
+    """Seeded recognizer outputs in the engine's layout: 2-4 recognizers, identical word ids / boxes, texts from a 3-word
+    alphabet (so majorities, equal-size groups and equal confidence sums all occur), confidences on a 0.05 grid."""
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    n_proc = int(rng.integers(2, 5))
+    names = ["default", "craft", "levocr", "tesseract"][:n_proc]
+    n_units = int(rng.integers(1, 4))
+    texts = ["ACME", "ACNE", "AGME"]
+    agg = {}
+    for name in names:
+        units = []
+        for u in range(n_units):
+            r2 = np.random.Generator(np.random.PCG64(9000 + seed * 31 + u))          # same word layout for every recognizer
+            nw = int(r2.integers(0, 7))
+            words = []
+            for i in r2.permutation(nw).tolist() if regions else range(nw):
+                words.append({"id": int(i), "text": texts[int(rng.integers(0, 3))],
+                              "confidence": round(float(rng.integers(1, 20)) * 0.05, 4),
+                              "box": [10 * int(i), 5 * u, 8, 4], "line": 1 + int(i) // 3, "word_index": int(i)})
+            unit = {"meta": {"page": u}, "words": words, "lines": []}
+            if regions:
+                unit["id"] = str(100 + u)
+            units.append(unit)
+        if regions:
+            agg[name] = {"regions": [{"id": 100 + u, "text": " ".join(w["text"] for w in un["words"]), "confidence": 0.5}
+                                     for u, un in enumerate(units)], "extended": units}
+        else:
+            agg[name] = units
+    reg = [{"id": 100 + u, "pageIndex": 0, "x": 0, "y": 0, "w": 50, "h": 20} for u in range(n_units)] if regions else None
+    return names, agg, reg

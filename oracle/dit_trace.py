@@ -166,3 +166,44 @@ def check_against(cands: Dict[str, np.ndarray], got_boxes: np.ndarray, iou_bar: 
             "kept_matched": int((kept & (best_c >= iou_bar)).sum()), "missing_kept": missing.tolist(),
             "foreign": foreign.tolist(),
             "unstable_present": int(((~kept) & (best_c >= iou_bar)).sum())}
+
+
+def explain_end_to_end(oracle, stages: Dict[str, object], out: Dict[str, object], page_hw, margin: float = 1.5
+                       ) -> Dict[str, object]:
+    """The whole argument for one page.  ``stages`` = the oracle's (``TorchDitOracle.detect(want_stages=True)``), ``out`` = the
+    other implementation's taps (``DitModel.debug_host``: rpn_heads, proposals, head, boxes, sizes).  Measures the error of
+    the continuous tensors (x ``margin``), runs the interval analysis with it and checks both box lists against it.
+    A match is IoU >= 0.999, or — for boxes a few pixels wide — every coordinate within the measured coordinate error."""
+    nh, nw = stages["resized_hw"]
+    sizes, strides = [tuple(s) for s in out["sizes"]], (4, 8, 16, 32, 64)
+    e_rpn = max(float(np.abs(g - r).max()) for g, r in zip(out["rpn_heads"], stages["rpn_heads"]))
+    es = margin * e_rpn
+    eb = 0.0
+    anchors = dt.grid_anchors(dt.cell_anchors(), sizes, strides)
+    for g, r, anc in zip(out["rpn_heads"], stages["rpn_heads"], anchors):
+        lg = torch.from_numpy(np.ascontiguousarray(r[:, :3])).reshape(-1)
+        idx = torch.argsort(lg, descending=True, stable=True)[:1200]
+        a = dt.apply_deltas(torch.from_numpy(np.ascontiguousarray(r[:, 3:15])).reshape(-1, 4)[idx], anc[idx], (1.0,) * 4)
+        b = dt.apply_deltas(torch.from_numpy(np.ascontiguousarray(g[:, 3:15])).reshape(-1, 4)[idx], anc[idx], (1.0,) * 4)
+        eb = max(eb, float((a - b).abs().max()))
+    eb *= margin
+    props = rpn_intervals(stages["rpn_heads"], sizes, strides, (nh, nw), es, eb)
+    chk_p = check_against(props, out["proposals"], coord_tol=eb)
+    nhwc = [np.ascontiguousarray(f) for f in stages["fpn"][:4]]
+    head_all = oracle.box_head(dt.roi_align(nhwc, (1 / 4, 1 / 8, 1 / 16, 1 / 32), props["boxes"]))
+    dist = np.abs(props["boxes"][:, None, :] - out["proposals"][None, :, :]).max(axis=2)
+    j, both = dist.argmin(axis=1), dist.min(axis=1) <= eb
+    pr_o = torch.softmax(torch.from_numpy(head_all[both, :2]), -1)[:, 0].numpy()
+    pr_g = torch.softmax(torch.from_numpy(np.ascontiguousarray(out["head"][j[both], :2])), -1)[:, 0].numpy()
+    w = (10.0, 10.0, 5.0, 5.0)
+    bx_o = dt.apply_deltas(torch.from_numpy(head_all[both, 2:6]), torch.from_numpy(props["boxes"][both]), w)
+    bx_g = dt.apply_deltas(torch.from_numpy(np.ascontiguousarray(out["head"][j[both], 2:6])),
+                           torch.from_numpy(np.ascontiguousarray(out["proposals"][j[both]])), w)
+    ep = margin * float(np.abs(pr_o - pr_g).max()) if both.any() else 0.0
+    eb2 = margin * float((bx_o - bx_g).abs().max()) if both.any() else 0.0
+    cands = final_intervals(head_all, props["boxes"], props["state"], (nh, nw), page_hw, ep, eb2)
+    scale = max(page_hw[0] / nh, page_hw[1] / nw)
+    return {"eps_logit": es, "eps_rpn_box_px": eb, "eps_prob": ep, "eps_final_box_px": eb2, "eps_page_px": eb2 * scale,
+            "proposals_on_both": int(both.sum()), "proposals_check": chk_p,
+            "boxes_check": check_against(cands, out["boxes"], coord_tol=eb2 * scale),
+            "boxes_check_iou_only": check_against(cands, out["boxes"])}

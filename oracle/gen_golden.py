@@ -371,9 +371,88 @@ def gen_renderer(out_dir):
     print("renderer", [len(c["text"]) for c in cases], len(doc))
 
 
+def _load_ref_voting_engine():
+    """marie/ocr/voting_ocr_engine.py, unmodified, by path.  Its package imports (recognizer classes, PSMode, the engine base
+    class, a JSON dump helper) are satisfied by placeholders — none of them is reached by the vote rules: an instance is made
+    without ``__init__`` and only ``voting_evaluator`` / ``get_words_by_vote_by_selector`` / ``group_candidates_by_selector``
+    run.  ``store_json_object`` (debug dumps under /tmp/marie) is a no-op."""
+    import importlib.util
+    import types
+
+    class _Quiet:
+        def info(self, *a, **k):
+            pass
+
+        error = warning = debug = info
+
+    names = {"marie": [], "marie.boxes": ["PSMode"], "marie.boxes.box_processor": ["BoxProcessor"],
+             "marie.constants": [], "marie.document": ["TrOcrProcessor"],
+             "marie.document.craft_ocr_processor": ["CraftOcrProcessor"],
+             "marie.document.lev_ocr_processor": ["LevenshteinOcrProcessor"],
+             "marie.document.ocr_processor": ["OcrProcessor"],
+             "marie.document.tesseract_ocr_processor": ["TesseractOcrProcessor"],
+             "marie.ocr": ["CoordinateFormat", "OcrEngine"], "marie.ocr.ocr_engine": [], "marie.utils": [],
+             "marie.utils.json": []}
+    saved = {n: sys.modules.get(n) for n in names}
+    for n, classes in names.items():
+        m = types.ModuleType(n)
+        for c in classes:
+            setattr(m, c, type(c, (), {}))
+        sys.modules[n] = m
+    sys.modules["marie.constants"].__model_path__ = "/nonexistent"
+    sys.modules["marie.boxes"].PSMode.SPARSE = "sparse"                 # default-argument values of extract(), never used
+    sys.modules["marie.ocr"].CoordinateFormat.XYXY = "xyxy"
+    sys.modules["marie.ocr.ocr_engine"].reset_bbox_cache = lambda: None
+    sys.modules["marie.utils.json"].store_json_object = lambda *a, **k: None
+    try:
+        spec = importlib.util.spec_from_file_location("ref_voting_ocr_engine", "/root/reference/marie/ocr/voting_ocr_engine.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for n, m in saved.items():
+            if m is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = m
+    eng = object.__new__(mod.VotingOcrEngine)
+    eng.logger = _Quiet()
+    return eng
+
+
+def gen_voting(out_dir):
+    """What the reference's own VotingOcrEngine.voting_evaluator returns for seeded recognizer outputs, page mode and region
+    mode (marie/ocr/voting_ocr_engine.py:186-482)."""
+    import contextlib
+    import copy
+    import io
+    import json
+    from collections import OrderedDict
+
+    from marie_icr_amd.weights import make_voting_case
+
+    eng = _load_ref_voting_engine()
+    cases = []
+    for seed in range(24):
+        regions = seed % 2 == 1
+        names, agg, reg = make_voting_case(seed, regions)
+        a = OrderedDict((n, copy.deepcopy(agg[n])) for n in names)
+        with contextlib.redirect_stdout(io.StringIO()):              # the reference prints its candidate tables
+            out = eng.voting_evaluator(a, a[names[0]], copy.deepcopy(reg))
+        cases.append({"seed": seed, "regions": regions, "expected": out})
+    # the reference's "nothing to evaluate" branch
+    _, _, reg = make_voting_case(1, True)
+    cases.append({"seed": 1, "regions": True, "empty": True, "expected": eng.voting_evaluator(OrderedDict(), None, copy.deepcopy(reg))})
+    with open(os.path.join(out_dir, "voting.json"), "w", encoding="UTF-8") as f:
+        json.dump({"cases": cases}, f)
+    print("voting", len(cases), sum(len(json.dumps(c)) for c in cases))
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if "--voting-only" in sys.argv:
+        gen_voting(out_dir)
+        return
     if "--renderer-only" in sys.argv:
         gen_renderer(out_dir)
         return

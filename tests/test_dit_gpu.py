@@ -167,11 +167,25 @@ def test_detector_fp32_end_to_end(ctx, small_case):
     for l, (f, r) in enumerate(zip(out["fpn"], stages["fpn"])):
         assert f.shape == r.shape
         assert np.abs(f - r).max() <= 2e-3, (l, np.abs(f - r).max())
-    # proposals / detections: discrete choices (top-k, NMS, thresholds) on maps that differ by ~1e-4, so compare as sets
-    for got, ref, frac in ((out["proposals"], stages["proposals"], 0.97), (out["boxes"], rboxes, 0.97)):
-        assert abs(len(got) - len(ref)) <= max(3, 0.03 * len(ref)), (len(got), len(ref))
-        iou = _iou_matrix(ref, got)
-        assert (iou.max(axis=1) >= 0.99).mean() >= frac
+    # proposals / detections: the discrete stages replayed on this run's own tensors give this run's boxes, and against the
+    # oracle every KEPT box has a partner at IoU >= 0.999 (or every coordinate within the measured error, < 0.01 px) and every
+    # other difference is a proven near-tie (oracle/dit_trace.py) — the bar of tests/test_fullsize_gpu.py on a second page
+    from oracle import dit_torch as dt
+    from oracle import dit_trace as tr
+
+    nh, nw = stages["resized_hw"]
+    ob, os_ = dt.rpn_proposals(out["rpn_heads"], out["sizes"], (4, 8, 16, 32, 64), (nh, nw), dt.cell_anchors())
+    assert len(ob) == len(out["proposals"]) and np.abs(ob - out["proposals"]).max() <= 1e-3
+    np.testing.assert_array_equal(os_, out["proposal_scores"])
+    ofb, ofs = dt.fast_rcnn_inference(out["head"], out["proposals"], (nh, nw), page.shape[:2])
+    assert len(ofb) == len(out["boxes"]) and np.abs(ofb - out["boxes"]).max() <= 2e-3
+    from oracle.dit_torch import TorchDitOracle
+
+    ex = tr.explain_end_to_end(TorchDitOracle(st, min_size=160, max_size=400), stages, out, page.shape[:2])
+    assert ex["eps_logit"] <= 2e-3 and ex["eps_page_px"] <= 1e-2, ex
+    for chk in (ex["proposals_check"], ex["boxes_check"]):
+        assert not chk["missing_kept"] and not chk["foreign"], ex
+    assert ex["boxes_check"]["kept"] >= 0.5 * len(rboxes), ex
     assert len(rboxes) > 10
     m.close()
 
@@ -194,25 +208,54 @@ def test_detector_f16_and_batch(ctx, small_case):
 
 
 def test_box_processor_vs_oracle_pipeline(ctx, small_case):
-    """BoxProcessorUlimDit's control flow (refinement passes + blackout + merge_boxes + lines + line numbers) in fp32
-    against the same flow on the CPU oracle."""
+    """BoxProcessorUlimDit's control flow (refinement passes + blackout + merge_boxes + aspect filter + lines + line numbers +
+    sort; marie/boxes/dit/ulim_dit_box_processor.py:499-832) against the same flow on the CPU oracle, decomposed so that
+    every comparison is exact:
+      (1) this class's flow (device blackout, native geometry) around the ORACLE's detector == the oracle pipeline;
+      (2) the oracle's flow around the GPU detector == this class end to end;
+    the detector itself is held to the oracle in test_detector_fp32_end_to_end."""
+    from marie_icr_amd._lib import PREC_F32
     from marie_icr_amd.box_processor import PSMode
     from marie_icr_amd.dit_box_processor import BoxProcessorUlimDit
     from oracle.dit_pipeline import OracleDitBoxProcessor
 
     st, page, *_ = small_case
     bp = BoxProcessorUlimDit(cuda=True, state=st, model="base", precision="f32", ctx=ctx, config=_config(ctx))
-    rects, frags, numbers, pred, lines = bp.extract_bounding_boxes("t", "k", page, PSMode.SPARSE)
     o = OracleDitBoxProcessor(st, min_size=160, max_size=400)
     orects, ofrags, onumbers, olines = o.extract_bounding_boxes(page)
+    assert len(orects) > 5
+
+    def same(a, b):
+        (r1, f1, n1, l1), (r2, f2, n2, l2) = a, b
+        np.testing.assert_array_equal(np.asarray(r1), np.asarray(r2))
+        assert len(f1) == len(f2) and all(np.array_equal(x, y) for x, y in zip(f1, f2))
+        assert list(n1) == list(n2)
+        np.testing.assert_array_equal(np.asarray(l1), np.asarray(l2))
+
+    # (1) oracle detector under the product control flow
+    gpu_detect = bp._detect
+    bp._detect = lambda page_dev, shape: o.det.detect(page_dev.cpu().numpy())
+    rects, frags, numbers, pred, lines = bp.extract_bounding_boxes("t", "k", page, PSMode.SPARSE)
+    same((rects, frags, numbers, lines), (orects, ofrags, onumbers, olines))
+    bp._detect = gpu_detect
+    # (2) GPU detector under the oracle's control flow == the product end to end
+    rects, frags, numbers, pred, lines = bp.extract_bounding_boxes("t", "k", page, PSMode.SPARSE)
+
+    class _GpuDet:
+        def detect(self, image):
+            return bp.model.detect_host(image[None])[0]
+
+    o2 = OracleDitBoxProcessor(st, min_size=160, max_size=400)
+    o2.det = _GpuDet()
+    same((rects, frags, numbers, lines), o2.extract_bounding_boxes(page))
     assert len(rects) == len(frags) == len(numbers) and len(rects) > 5
-    assert abs(len(rects) - len(orects)) <= max(2, 0.05 * len(orects)), (len(rects), len(orects))
-    a = np.asarray(rects, np.float32); b = np.asarray(orects, np.float32)
-    a[:, 2:] += a[:, :2]; b[:, 2:] += b[:, :2]
-    assert (_iou_matrix(b, a).max(axis=1) >= 0.98).mean() >= 0.9
     for r, f in zip(rects, frags):
         np.testing.assert_array_equal(f, page[r[1]:r[1] + r[3], r[0]:r[0] + r[2]])
-    assert abs(len(lines) - len(olines)) <= 1
+    # and the two ends agree to the extent the detector's near-ties allow (reported, not the parity argument)
+    a = np.asarray(rects, np.float32); b = np.asarray(orects, np.float32)
+    a[:, 2:] += a[:, :2]; b[:, 2:] += b[:, :2]
+    print("pipeline end to end: matched at IoU>=0.999:", float((_iou_matrix(b, a).max(axis=1) >= 0.999).mean()),
+          len(rects), len(orects))
     # RAW_LINE / WORD: the whole image is the single fragment
     r2 = bp.extract_bounding_boxes("t", "k", page, PSMode.RAW_LINE)
     assert r2[0] == [[0, 0, page.shape[1], page.shape[0]]] and r2[2] == [0]

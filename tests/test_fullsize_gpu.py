@@ -119,46 +119,13 @@ def test_dit_base_fp32_full_page(ctx, page, dit_case):
     assert np.abs(ofb - out["boxes"]).max() <= 2e-3
 
     # ---- end to end: every miss is a near-tie (oracle/dit_trace.py) ----
-    es = 1.5 * max(e_rpn)                                           # bound on |d logit| and |d delta|, with margin
-    # coordinate error of decoded RPN boxes: decode the same candidates with both sets of deltas
-    eb = 0.0
-    anchors = dt.grid_anchors(dt.cell_anchors(), sizes, strides)
-    import torch
-
-    for g, r, anc in zip(out["rpn_heads"], stages["rpn_heads"], anchors):
-        lg = torch.from_numpy(r[:, :3].reshape(-1))
-        idx = torch.argsort(lg, descending=True, stable=True)[:1200]
-        a = dt.apply_deltas(torch.from_numpy(r[:, 3:15].reshape(-1, 4))[idx], anc[idx], (1.0,) * 4)
-        b = dt.apply_deltas(torch.from_numpy(g[:, 3:15].reshape(-1, 4))[idx], anc[idx], (1.0,) * 4)
-        eb = max(eb, float((a - b).abs().max()))
-    eb *= 1.5
-    assert eb <= 5e-2, eb
-    props = tr.rpn_intervals(stages["rpn_heads"], sizes, strides, (nh, nw), es, eb)
-    chk_p = tr.check_against(props, out["proposals"], coord_tol=eb)
+    ex = tr.explain_end_to_end(o, stages, out, (PAGE_H, PAGE_W))
+    chk_p, chk = ex["proposals_check"], ex["boxes_check"]
+    assert ex["eps_logit"] <= 2e-3 and ex["eps_prob"] <= 2e-3 and ex["eps_page_px"] <= 1e-2, ex    # a detection moves < 0.01 px
+    assert ex["proposals_on_both"] >= 0.9 * len(out["proposals"])
     assert not chk_p["missing_kept"] and not chk_p["foreign"], chk_p
-    # second stage for every proposal that may exist (the oracle's box head on the oracle's maps)
-    pooled_all = dt.roi_align(nhwc, (1 / 4, 1 / 8, 1 / 16, 1 / 32), props["boxes"])
-    head_all = o.box_head(pooled_all)
-    # measured second-stage error on the proposals both runs hold
-    dist = np.abs(props["boxes"][:, None, :] - out["proposals"][None, :, :]).max(axis=2)
-    j = dist.argmin(axis=1)
-    both = dist.min(axis=1) <= eb
-    assert both.sum() >= 0.9 * len(out["proposals"])
-    pr_o = torch.softmax(torch.from_numpy(head_all[both, :2]), -1)[:, 0].numpy()
-    pr_g = torch.softmax(torch.from_numpy(out["head"][j[both], :2]), -1)[:, 0].numpy()
-    bx_o = dt.apply_deltas(torch.from_numpy(head_all[both, 2:6]), torch.from_numpy(props["boxes"][both]), (10.0, 10.0, 5.0, 5.0))
-    bx_g = dt.apply_deltas(torch.from_numpy(out["head"][j[both], 2:6]), torch.from_numpy(out["proposals"][j[both]]),
-                           (10.0, 10.0, 5.0, 5.0))
-    ep = 1.5 * float(np.abs(pr_o - pr_g).max())
-    eb2 = 1.5 * float((bx_o - bx_g).abs().max())
-    assert ep <= 2e-3 and eb2 * PAGE_H / nh <= 1e-2, (ep, eb2)     # page-coordinate error of a detection below 0.01 px
-    cands = tr.final_intervals(head_all, props["boxes"], props["state"], (nh, nw), (PAGE_H, PAGE_W), ep, eb2)
-    chk_strict = tr.check_against(cands, out["boxes"])                     # IoU >= 0.999 only
-    chk = tr.check_against(cands, out["boxes"], coord_tol=eb2 * PAGE_H / nh)  # or every coordinate within the measured error
-    rep = {"fpn_max_abs_err": e_fpn, "rpn_head_max_abs_err": e_rpn, "eps_logit": es, "eps_rpn_box_px": eb, "eps_prob": ep,
-           "eps_final_box_px": eb2, "oracle_boxes": len(rboxes), "gpu_boxes": len(out["boxes"]),
-           "oracle_proposals": len(stages["proposals"]), "gpu_proposals": len(out["proposals"]),
-           "proposals_check": chk_p, "boxes_check": chk, "boxes_check_iou_only": chk_strict,
+    rep = {"fpn_max_abs_err": e_fpn, "rpn_head_max_abs_err": e_rpn, "oracle_boxes": len(rboxes), "gpu_boxes": len(out["boxes"]),
+           "oracle_proposals": len(stages["proposals"]), "gpu_proposals": len(out["proposals"]), **ex,
            "matched_iou_0.999": _match(rboxes, out["boxes"], 0.999), "matched_iou_0.99": _match(rboxes, out["boxes"], 0.99)}
     _report("dit_base_fp32", rep)
     # the bar: IoU >= 0.999 for every box whose existence does not hang on a near-tie; nothing unexplained on either side

@@ -1,5 +1,5 @@
 """VotingOcrEngine's evaluator (marie/ocr/voting_ocr_engine.py:186-482) restated in marie_icr_amd.ocr_engine — host logic,
-checked on hand-built recognizer outputs (the reference module imports its whole package and cannot be loaded here)."""
+checked on hand-built recognizer outputs and against goldens written by the reference's own evaluator (bottom of this file)."""
 from collections import OrderedDict
 from copy import deepcopy
 
@@ -61,3 +61,34 @@ def test_region_mode_evaluator_and_empty_aggregate():
     assert r["confidence"] == round((0.5 + 0.9) / 2, 4)
     empty = voting_evaluator(OrderedDict(), None, deepcopy(regions))
     assert empty["regions"][0]["text"] == "" and empty["regions"][0]["confidence"] == 0
+
+
+# ---- goldens written by the reference's own VotingOcrEngine.voting_evaluator (oracle/gen_golden.py --voting-only loads
+# marie/ocr/voting_ocr_engine.py by path): 12 page-mode and 12 region-mode seeded cases with 2-4 recognizers, plus the
+# "nothing to evaluate" branch
+def _golden_cases():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "voting.json"), encoding="UTF-8") as f:
+        return json.load(f)["cases"]
+
+
+def test_evaluator_matches_reference_goldens():
+    from marie_icr_amd.weights import make_voting_case
+
+    n_conf = n_vote = n_default = 0
+    for case in _golden_cases():
+        names, agg, reg = make_voting_case(case["seed"], case["regions"])
+        if case.get("empty"):
+            got = voting_evaluator(OrderedDict(), None, deepcopy(reg))
+        else:
+            a = OrderedDict((n, deepcopy(agg[n])) for n in names)
+            got = voting_evaluator(a, a[names[0]], deepcopy(reg))
+        assert got == case["expected"], case["seed"]
+        units = got if not case["regions"] else got.get("extended", [])
+        for u in units:
+            for w in u["words"]:
+                t = w["strategy"]["type"]
+                n_conf += t == "confidence"; n_vote += t == "voting"; n_default += t == "default"
+    assert n_conf > 5 and n_vote > 20 and n_default > 5          # every rule of the evaluator is exercised by the cases
