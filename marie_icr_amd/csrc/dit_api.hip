@@ -445,7 +445,7 @@ extern "C" int mhip_dit_debug_host(mhip_dit* m, const uint8_t* page_host, int h,
 }
 
 // same, plus the inputs of the two discrete stages (RPN selection, FastRCNN inference) as this run computed them: the
-// parity tests replay the oracle's discrete stages on them
+// parity tests replay the CPU restatement of the discrete stages on them
 extern "C" int mhip_dit_debug_taps_host(mhip_dit* m, const uint8_t* page_host, int h, int w, float* boxes_host,
                                         float* scores_host, int* count_host, float* const* fpn5, float* const* rpn_head5,
                                         float* prop_boxes, float* prop_scores, int* prop_count, float* box_head) {

@@ -126,7 +126,7 @@ class BoxProcessorUlimDit:
 
     def _detect(self, page_dev, shape):
         """One detector forward on a device page -> (boxes xyxy fp32 page coordinates, scores).  The one call the parity tests
-        swap (oracle detector under this class's control flow, and the other way round)."""
+        swap (a CPU detector under this class's control flow, and the other way round)."""
         import torch
 
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
