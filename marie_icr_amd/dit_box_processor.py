@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Any, Dict, Optional, Tuple
+from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -87,7 +87,7 @@ class BoxProcessorUlimDit:
 
     def __init__(self, work_dir: str = "/tmp/boxes", models_dir: Optional[str] = None, cuda: bool = False,
                  refinement: bool = True, *, state: Optional[Dict[str, np.ndarray]] = None, model: str = "large",
-                 precision: str = "f16", device_id: int = 0, ctx: Optional[Context] = None, config=None):
+                 precision: str = "f16", device_id: int = 0, ctx: Optional[Context] = None, config=None, det_batch: int = 8):
         if not cuda:
             raise MarieHipError("BoxProcessorUlimDit here is the MI355X path; cuda=False has no implementation")
         self.work_dir = work_dir
@@ -107,6 +107,7 @@ class BoxProcessorUlimDit:
             state = {k: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for k, v in sd.items()}
         prec = {"f16": PREC_F16, "fp16": PREC_F16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
         self.model = DitModel(self.ctx, state, model=model, precision=prec, config=config)
+        self.det_batch = int(det_batch)
         self.min_size_test = [self.model.cfg.min_size_test, self.model.cfg.min_size_test]
 
     # -- device page helpers -------------------------------------------------------------------------------------
@@ -124,19 +125,22 @@ class BoxProcessorUlimDit:
               "mhip_blackout_bboxes")
         return bool(changed.value)
 
-    def _detect(self, page_dev, shape):
-        """One detector forward on a device page -> (boxes xyxy fp32 page coordinates, scores).  The one call the parity tests
-        swap (a CPU detector under this class's control flow, and the other way round)."""
+    def _detect_batch(self, page_devs, shape):
+        """One detector forward over device pages of one shape -> [(boxes xyxy fp32 page coordinates, scores)] per page.  The one
+        call the parity tests swap (a CPU detector under this class's control flow, and the other way round)."""
         import torch
 
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        (boxes, scores), = self.model.detect_device([page_dev.data_ptr()], shape[0], shape[1])
-        return boxes, scores
+        out = []
+        for s0 in range(0, len(page_devs), self.det_batch):
+            chunk = page_devs[s0:s0 + self.det_batch]
+            out.extend(self.model.detect_device([d.data_ptr() for d in chunk], shape[0], shape[1]))
+        return out
 
     # -- page segmentation ------------------------------------------------------------------------------------------
-    def psm_sparse_step(self, page_dev, shape, adj_x: int, adj_y: int):
-        """reference: ulim_dit_box_processor.py:424-497.  ``page_dev``: CUDA uint8 tensor (h, w, 3) BGR."""
-        boxes, scores = self._detect(page_dev, shape)
+    @staticmethod
+    def _post_step(boxes, scores, shape, adj_x: int, adj_y: int):
+        """reference: ulim_dit_box_processor.py:441-497 (what psm_sparse_step does with the predictor's output)."""
         if len(boxes) == 0:
             return [], [], []
         bboxes = boxes
@@ -153,56 +157,87 @@ class BoxProcessorUlimDit:
         # as in the reference, classes / scores keep the detector's length and order (they are not merged)
         return bboxes, np.zeros((len(scores),), np.int64), scores
 
+    def psm_sparse_step(self, page_dev, shape, adj_x: int, adj_y: int):
+        """reference: ulim_dit_box_processor.py:424-497.  ``page_dev``: CUDA uint8 tensor (h, w, 3) BGR."""
+        (boxes, scores), = self._detect_batch([page_dev], shape)
+        return self._post_step(boxes, scores, shape, adj_x, adj_y)
+
     def psm_sparse(self, image: np.ndarray, bbox_optimization: Optional[bool] = False,
                    bbox_context_aware: Optional[bool] = True, bbox_refinement: Optional[bool] = None,
                    enable_visualization: Optional[bool] = False):
         """reference: ulim_dit_box_processor.py:499-658."""
-        adj_x = adj_y = 0
-        if image.shape[0] < self.min_size_test[0] or image.shape[1] < self.min_size_test[1]:
-            image, coord = resize_image(image, (self.min_size_test[0], self.min_size_test[1]), keep_max_size=True,
-                                        ctx=self.ctx)
-            adj_x, adj_y = coord[0], coord[1]
-        refinement = self.refinement if bbox_refinement is None else bbox_refinement
-        refinement_steps = 3 if refinement else 1
-        bboxes, classes, scores = [], [], []
-        page_dev = self._upload(image)           # the refinement image: boxes found so far are painted white on it
-        for i in range(refinement_steps):
-            bboxes_, classes_, scores_ = self.psm_sparse_step(page_dev, image.shape, adj_x, adj_y)
-            changed = self._blackout(page_dev, bboxes_) if len(bboxes_) else False
-            if i == 0:
-                bboxes.extend(bboxes_)
-                classes.extend(classes_)
-                scores.extend(scores_)
-                continue
-            if not changed:
-                break
-            if len(bboxes_) == 0:
-                break
-            ious = box_iou(np.asarray(bboxes, np.float32), np.asarray(bboxes_, np.float32))
-            tgt = np.unique(np.nonzero(ious > 0.1)[1])
-            bboxes_ = np.delete(bboxes_, tgt, axis=0)
-            classes_ = np.delete(classes_, tgt, axis=0)
-            scores_ = np.delete(scores_, tgt, axis=0)
-            bboxes.extend(bboxes_)
-            classes.extend(classes_)
-            scores.extend(scores_)
+        return self.psm_sparse_batch([image], bbox_optimization, bbox_context_aware, bbox_refinement)[0][:5]
+
+    def psm_sparse_batch(self, images, bbox_optimization: Optional[bool] = False, bbox_context_aware: Optional[bool] = True,
+                         bbox_refinement: Optional[bool] = None):
+        """``psm_sparse`` (ulim_dit_box_processor.py:499-658) for several pages at once: every refinement pass runs the
+        detector over all pages that are still active, batched by page shape (``det_batch`` pages per forward; batching does
+        not change a page's boxes).  Per page the control flow is the reference's: pass 0 keeps everything; a later pass stops
+        the page when the blackout changed nothing or nothing was found, else drops boxes overlapping (IoU > 0.1) earlier
+        ones.  Returns per page ``(bboxes, classes, scores, lines, classes, device page or None)`` — the last item is the
+        pristine page in HBM when the page was not framed (fragments can then be read where they are)."""
         if bbox_optimization:
             raise NotImplementedError("bbox_optimization (crop_to_content_box) is not part of this build")
-        bb, cc, sc = [], [], []
-        for box, cls, score in zip(bboxes, classes, scores):        # names swapped as in the reference (Q4): keeps wide boxes
-            h = box[2] - box[0]
-            w = box[3] - box[1]
-            if w / h < 2.5:
-                bb.append(box)
-                cc.append(cls)
-                sc.append(score)
-        bboxes, classes, scores = np.array(bb), np.array(cc), np.array(sc)
-        if len(bboxes) == 0:
-            return [], [], [], [], []
-        ind = np.lexsort((bboxes[:, 0], bboxes[:, 1]))
-        bboxes = bboxes[ind]
-        lines = lines_from_bboxes(image, bboxes)
-        return bboxes, classes, scores, lines, classes
+        refinement = self.refinement if bbox_refinement is None else bbox_refinement
+        steps = 3 if refinement else 1
+        pages = []
+        for image in images:
+            adj_x = adj_y = 0
+            framed = image
+            if image.shape[0] < self.min_size_test[0] or image.shape[1] < self.min_size_test[1]:
+                framed, coord = resize_image(image, (self.min_size_test[0], self.min_size_test[1]), keep_max_size=True,
+                                             ctx=self.ctx)
+                adj_x, adj_y = coord[0], coord[1]
+            dev = self._upload(framed)
+            # the refinement image: boxes found so far are painted white on it; the pristine copy stays for the fragments
+            work = dev.clone() if steps > 1 else dev
+            pages.append({"image": framed, "adj": (adj_x, adj_y), "dev": dev if framed is image else None, "work": work,
+                          "bboxes": [], "classes": [], "scores": [], "active": True})
+        for i in range(steps):
+            groups: Dict[Tuple[int, ...], list] = {}
+            for pg in pages:
+                if pg["active"]:
+                    groups.setdefault(tuple(pg["image"].shape), []).append(pg)
+            if not groups:
+                break
+            for shape, group in groups.items():
+                dets = self._detect_batch([pg["work"] for pg in group], shape)
+                for pg, (boxes, scores) in zip(group, dets):
+                    bboxes_, classes_, scores_ = self._post_step(boxes, scores, shape, *pg["adj"])
+                    # a single pass never looks at the whitened page again: the blackout is skipped (output-invariant)
+                    changed = self._blackout(pg["work"], bboxes_) if (len(bboxes_) and steps > 1) else False
+                    if i == 0:
+                        pg["bboxes"].extend(bboxes_)
+                        pg["classes"].extend(classes_)
+                        pg["scores"].extend(scores_)
+                        continue
+                    if not changed or len(bboxes_) == 0:
+                        pg["active"] = False
+                        continue
+                    ious = box_iou(np.asarray(pg["bboxes"], np.float32), np.asarray(bboxes_, np.float32))
+                    tgt = np.unique(np.nonzero(ious > 0.1)[1])
+                    pg["bboxes"].extend(np.delete(bboxes_, tgt, axis=0))
+                    pg["classes"].extend(np.delete(classes_, tgt, axis=0))
+                    pg["scores"].extend(np.delete(scores_, tgt, axis=0))
+        out = []
+        for pg in pages:
+            bb, cc, sc = [], [], []
+            for box, cls, score in zip(pg["bboxes"], pg["classes"], pg["scores"]):   # names swapped as in the reference (Q4)
+                h = box[2] - box[0]
+                w = box[3] - box[1]
+                if w / h < 2.5:
+                    bb.append(box)
+                    cc.append(cls)
+                    sc.append(score)
+            bboxes, classes, scores = np.array(bb), np.array(cc), np.array(sc)
+            if len(bboxes) == 0:
+                out.append(([], [], [], [], [], pg["dev"]))
+                continue
+            ind = np.lexsort((bboxes[:, 0], bboxes[:, 1]))
+            bboxes = bboxes[ind]
+            lines = lines_from_bboxes(pg["image"], bboxes)
+            out.append((bboxes, classes, scores, lines, classes, pg["dev"]))
+        return out
 
     def psm_word(self, image):
         return self.psm_sparse(image)
@@ -220,47 +255,65 @@ class BoxProcessorUlimDit:
                                bbox_context_aware: Optional[bool] = True, bbox_refinement: Optional[bool] = None
                                ) -> Tuple[Any, Any, Any, Any, Any]:
         """reference: ulim_dit_box_processor.py:676-832."""
-        if img is None:
-            raise Exception("Input image can't be empty")
-        if not isinstance(img, np.ndarray):
-            if hasattr(img, "convert"):      # PIL image -> BGR ndarray
-                img = np.array(img.convert("RGB"), dtype=np.uint8)[:, :, ::-1].copy()
-            else:
-                raise ValueError("Expected image in numpy format")
-        image = img.copy()
-        lines_bboxes = []
-        if psm == PSMode.SPARSE:
-            bboxes, polys, scores, lines_bboxes, classes = self.psm_sparse(image, bbox_optimization, bbox_context_aware,
-                                                                          bbox_refinement)
-        elif psm == PSMode.LINE:
-            bboxes, polys, scores, lines_bboxes, classes = self.psm_line(image)
-        elif psm == PSMode.MULTI_LINE:
-            bboxes, polys, scores, lines_bboxes, classes = self.psm_multiline(image)
-        elif psm == PSMode.RAW_LINE or psm == PSMode.WORD:
-            h, w = image.shape[:2]
-            return [[0, 0, w, h]], [image], [0], dict(), lines_bboxes
-        else:
+        return self.extract_bounding_boxes_batch(_id, key, [img], psm, bbox_optimization, bbox_context_aware,
+                                                 bbox_refinement)[0]
+
+    def extract_bounding_boxes_batch(self, _id, key, imgs, psm=PSMode.SPARSE, bbox_optimization: Optional[bool] = False,
+                                     bbox_context_aware: Optional[bool] = True, bbox_refinement: Optional[bool] = None):
+        """``extract_bounding_boxes`` (ulim_dit_box_processor.py:676-832) for a list of pages with the detector batched over
+        them; one 5-tuple per page, identical to what the per-page call returns.  ``fragments`` is a ``FragmentList``: numpy
+        windows of the ORIGINAL image as in the reference, plus — when the page sits in HBM unframed — the device window each
+        was cut from."""
+        from .fragments import FragmentList
+
+        checked = []
+        for img in imgs:
+            if img is None:
+                raise Exception("Input image can't be empty")
+            if not isinstance(img, np.ndarray):
+                if hasattr(img, "convert"):      # PIL image -> BGR ndarray
+                    img = np.array(img.convert("RGB"), dtype=np.uint8)[:, :, ::-1].copy()
+                else:
+                    raise ValueError("Expected image in numpy format")
+            checked.append(img)
+        if psm in (PSMode.RAW_LINE, PSMode.WORD):
+            return [([[0, 0, im.shape[1], im.shape[0]]], [im.copy()], [0], dict(), []) for im in checked]
+        if psm not in (PSMode.SPARSE, PSMode.LINE, PSMode.MULTI_LINE):
             raise Exception(f"PSM mode not supported : {psm}")
-        rect_from_poly, rect_line_numbers, fragments = [], [], []
-        if len(bboxes):
-            bi = np.asarray(bboxes).astype(np.int32)
-            xywh = np.stack([bi[:, 0], bi[:, 1], bi[:, 2] - bi[:, 0], bi[:, 3] - bi[:, 1]], axis=1)
-            numbers = find_line_numbers(lines_bboxes, xywh)
-            for i in range(len(bboxes)):
-                if classes[i] == 0:
-                    x0, y0, w, h = xywh[i]
-                    fragments.append(img[y0:y0 + h, x0:x0 + w:])
-                    rect_from_poly.append([x0, y0, w, h])
-                    rect_line_numbers.append(numbers[i])
-        if len(bboxes) > 0:
-            # the reference indexes rect_line_numbers by detection index here, so an (impossible on this model) non-text
-            # class would mis-align them; with one class the two index spaces coincide
-            aug = np.array([[b[0], b[1], b[2], b[3], rect_line_numbers[i]] for i, b in enumerate(bboxes)])
-            ind = np.lexsort((aug[:, 0], aug[:, 4]))
-            bboxes = bboxes[ind]
-            scores = scores[ind]
-            rect_from_poly = np.array(rect_from_poly)[ind]
-            fragments = [fragments[i] for i in ind]
-        fragments = [np.array(f, dtype=np.uint8) for f in fragments]
-        prediction_result = {"bboxes": bboxes, "polys": bboxes, "scores": scores, "heatmap": None}
-        return rect_from_poly, fragments, rect_line_numbers, prediction_result, lines_bboxes
+        if psm == PSMode.SPARSE:
+            found = self.psm_sparse_batch(checked, bbox_optimization, bbox_context_aware, bbox_refinement)
+        else:
+            found = self.psm_sparse_batch(checked)
+        results = []
+        for img, (bboxes, polys, scores, lines_bboxes, classes, dev) in zip(checked, found):
+            rect_from_poly, rect_line_numbers, fragments, windows = [], [], [], []
+            if len(bboxes):
+                bi = np.asarray(bboxes).astype(np.int32)
+                xywh = np.stack([bi[:, 0], bi[:, 1], bi[:, 2] - bi[:, 0], bi[:, 3] - bi[:, 1]], axis=1)
+                numbers = find_line_numbers(lines_bboxes, xywh)
+                H, W = img.shape[:2]
+                base = dev.data_ptr() if dev is not None else 0
+                for i in range(len(bboxes)):
+                    if classes[i] == 0:
+                        x0, y0, w, h = (int(v) for v in xywh[i])
+                        frag = img[y0:y0 + h, x0:x0 + w:]
+                        fragments.append(frag)
+                        windows.append((base + (y0 * W + x0) * 3, frag.shape[0], frag.shape[1], W * 3, 3))
+                        rect_from_poly.append([x0, y0, w, h])
+                        rect_line_numbers.append(numbers[i])
+            if len(bboxes) > 0:
+                # the reference indexes rect_line_numbers by detection index here, so an (impossible on this model) non-text
+                # class would mis-align them; with one class the two index spaces coincide
+                aug = np.array([[b[0], b[1], b[2], b[3], rect_line_numbers[i]] for i, b in enumerate(bboxes)])
+                ind = np.lexsort((aug[:, 0], aug[:, 4]))
+                bboxes = bboxes[ind]
+                scores = scores[ind]
+                rect_from_poly = np.array(rect_from_poly)[ind]
+                fragments = [fragments[i] for i in ind]
+                windows = [windows[i] for i in ind]
+            usable = dev is not None and img.ndim == 3 and all(f.size > 0 for f in fragments)
+            fragments = FragmentList([np.array(f, dtype=np.uint8) for f in fragments], windows if usable else None,
+                                     [dev] if usable else ())
+            prediction_result = {"bboxes": bboxes, "polys": bboxes, "scores": scores, "heatmap": None}
+            results.append((rect_from_poly, fragments, rect_line_numbers, prediction_result, lines_bboxes))
+        return results

@@ -118,21 +118,80 @@ class OcrEngine:
         """reference: ocr_engine.py:154-221."""
         if kwargs.get("crop_to_content", False):
             raise NotImplementedError("crop_to_content is not available on the MI355X path")
+        if hasattr(box_processor, "extract_bounding_boxes_batch") and hasattr(icr_processor, "recognize_pages"):
+            return self._fullpage_batched(frames, queue_id, checksum, pms_mode, coordinate_format, box_processor,
+                                          icr_processor)
         results = []
         for i, img in enumerate(frames):
             overlay = img                                   # padding == 0: the white canvas equals the page
             boxes, img_fragments, lines, _, line_bboxes = box_processor.extract_bounding_boxes(
                 queue_id, checksum, overlay, pms_mode)
             result, _ = icr_processor.recognize(queue_id, checksum, overlay, boxes, img_fragments, lines)
-            if CoordinateFormat.XYXY == coordinate_format:
-                for word in result["words"]:
-                    x, y, w, h = word["box"]
-                    word["box"] = [x, y, x + w, y + h]
-            result["meta"]["page"] = i
-            result["meta"]["lines"] = lines
-            result["meta"]["lines_bboxes"] = line_bboxes
-            result["meta"]["format"] = coordinate_format.name.lower()
-            results.append(result)
+            results.append(self._finish_page(result, i, lines, line_bboxes, coordinate_format))
+        return results
+
+    @staticmethod
+    def _finish_page(result, i, lines, line_bboxes, coordinate_format):
+        """reference: ocr_engine.py:201-219."""
+        if CoordinateFormat.XYXY == coordinate_format:
+            for word in result["words"]:
+                x, y, w, h = word["box"]
+                word["box"] = [x, y, x + w, y + h]
+        result["meta"]["page"] = i
+        result["meta"]["lines"] = lines
+        result["meta"]["lines_bboxes"] = line_bboxes
+        result["meta"]["format"] = coordinate_format.name.lower()
+        return result
+
+    page_batch = 32      # pages per detector / recognizer batch of the batched full-page path
+
+    def _fullpage_batched(self, frames, queue_id, checksum, pms_mode, coordinate_format, box_processor, icr_processor):
+        """The per-page loop of ocr_engine.py:172-221 with both models batched: ``page_batch`` pages go through the detector
+        together (same-size pages share a forward) and their fragments are pooled into one recognizer batch.  A page's result
+        is what the per-page loop returns (tests/test_pipeline_gpu.py).  With more than one batch and the two processors on
+        different contexts, the detector of batch k + 1 runs on its own stream and host thread under the recognizer of batch k."""
+        import queue
+        import threading
+
+        import torch
+
+        B = max(1, int(self.page_batch))
+        chunks = [list(range(s, min(len(frames), s + B))) for s in range(0, len(frames), B)]
+
+        def detect(idx):
+            return box_processor.extract_bounding_boxes_batch(queue_id, checksum, [frames[i] for i in idx], pms_mode)
+
+        def recognize(idx, found):
+            pages = [(frames[i], f[0], f[1], f[2]) for i, f in zip(idx, found)]
+            recs = icr_processor.recognize_pages(queue_id, checksum, pages)
+            return [self._finish_page(r, i, f[2], f[4], coordinate_format) for i, f, (r, _) in zip(idx, found, recs)]
+
+        overlap = len(chunks) > 1 and getattr(box_processor, "ctx", None) is not getattr(icr_processor, "ctx", None)
+        results: List[Dict] = []
+        if not overlap:
+            for idx in chunks:
+                results.extend(recognize(idx, detect(idx)))
+            return results
+        q: "queue.Queue" = queue.Queue(maxsize=2)
+        det_stream = torch.cuda.Stream()
+
+        def producer():
+            try:
+                with torch.cuda.stream(det_stream):
+                    for idx in chunks:
+                        q.put((idx, detect(idx)))
+            except BaseException as e:              # surfaced on the consumer side
+                q.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        for _ in chunks:
+            item = q.get()
+            if isinstance(item, BaseException):
+                th.join()
+                raise item
+            results.extend(recognize(*item))
+        th.join()
         return results
 
     def _process_extract_regions(self, frames, queue_id, checksum, pms_mode, regions, box_processor, icr_processor,

@@ -46,9 +46,8 @@ class OcrProcessor:
             return r["text"], r["confidence"]
         return None, 0
 
-    def recognize(self, _id, key, img: np.ndarray, boxes, fragments, lines,
-                  return_overlay: Optional[bool] = False) -> Tuple[Dict, Optional[np.ndarray]]:
-        """reference: ocr_processor.py:87-267."""
+    @staticmethod
+    def _check_inputs(img, boxes, fragments, lines):
         if img is None:
             raise Exception("Input image can't be empty")
         if not isinstance(img, np.ndarray):
@@ -63,15 +62,45 @@ class OcrProcessor:
             raise Exception("Expected image in numpy format but got {}".format(type(img)))
         assert len(boxes) == len(fragments), "You must provide the same number of box groups as images."
         assert len(boxes) == len(lines), "You must provide the same number of lines as boxes."
+        return img
 
-        shape = img.shape
-        meta = {"imageSize": {"width": img.shape[1], "height": img.shape[0]}, "page": 0, "lang": "en"}
+    def recognize(self, _id, key, img: np.ndarray, boxes, fragments, lines,
+                  return_overlay: Optional[bool] = False) -> Tuple[Dict, Optional[np.ndarray]]:
+        """reference: ocr_processor.py:87-267."""
+        img = self._check_inputs(img, boxes, fragments, lines)
+        if len(boxes) == 0:                                 # blank page (:147-154)
+            return self._assemble(img.shape, boxes, lines, [], True)
+        results = self.recognize_from_fragments(fragments)
+        return self._assemble(img.shape, boxes, lines, results, return_overlay)
+
+    def recognize_pages(self, _id, key, pages, return_overlay: Optional[bool] = False):
+        """``recognize`` for several pages with ONE recognizer call: ``pages`` = [(img, boxes, fragments, lines), ...]; the
+        fragments of all pages are pooled into a single ``recognize_from_fragments`` batch (the reference calls its
+        recognizer page by page, ocr_engine.py:172-199; a page's result does not depend on its batch).  Returns the list of
+        ``recognize`` results."""
+        from .fragments import FragmentList
+
+        checked = [(self._check_inputs(img, b, f, l), b, f, l) for img, b, f, l in pages]
+        pooled = FragmentList.concat([f for _, b, f, _ in checked if len(b)])
+        results = self.recognize_from_fragments(pooled) if len(pooled) else []
+        assert len(results) == len(pooled), "You must provide the same number of results as fragments."
+        out, k = [], 0
+        for img, boxes, fragments, lines in checked:
+            if len(boxes) == 0:
+                out.append(self._assemble(img.shape, boxes, lines, [], True))
+                continue
+            out.append(self._assemble(img.shape, boxes, lines, results[k:k + len(fragments)], return_overlay))
+            k += len(fragments)
+        return out
+
+    def _assemble(self, shape, boxes, lines, results, return_overlay):
+        """Words in reading order, lines, confidences — reference: ocr_processor.py:140-267."""
+        meta = {"imageSize": {"width": shape[1], "height": shape[0]}, "page": 0, "lang": "en"}
         if len(boxes) == 0:                                 # blank page (:147-154)
             overlay_image = np.ones((shape[0], shape[1], 3), dtype=np.uint8) * 255
             return {"meta": meta, "words": [], "lines": []}, overlay_image
 
-        results = self.recognize_from_fragments(fragments)
-        assert len(results) == len(fragments), "You must provide the same number of results as fragments."
+        assert len(results) == len(boxes), "You must provide the same number of results as fragments."
         words = []
         boxes = np.array(boxes)
         lines = np.array(lines)
@@ -85,17 +114,19 @@ class OcrProcessor:
         line_results = np.empty(len(unique_line_ids), dtype=object)
         aligned_words = []
         word_index = 0
+        by_line: Dict[int, list] = {}                       # the reference scans all words per line id; same order, one pass
+        for word in words:
+            by_line.setdefault(int(word["line"]), []).append(word)
         for i, line_numer in enumerate(unique_line_ids):
             word_ids, box_picks, _w, _conf = [], [], [], []
-            for word in words:
-                if line_numer == word["line"]:
-                    word["word_index"] = word_index
-                    word_ids.append(word["id"])
-                    box_picks.append(word["box"])
-                    _w.append(word["text"])
-                    _conf.append(word["confidence"])
-                    aligned_words.append(word)
-                    word_index += 1
+            for word in by_line.get(int(line_numer), ()):
+                word["word_index"] = word_index
+                word_ids.append(word["id"])
+                box_picks.append(word["box"])
+                _w.append(word["text"])
+                _conf.append(word["confidence"])
+                aligned_words.append(word)
+                word_index += 1
             if len(box_picks) == 0:
                 raise Exception("Every word needs to be associated with a box")
             line_results[i] = {"line": i + 1, "wordids": word_ids, "text": " ".join(_w),

@@ -218,15 +218,24 @@ class TrOcrProcessor(OcrProcessor):
         return self.bpe.decode(s) if self.bpe is not None else s
 
     def recognize_from_fragments(self, src_images, **kwargs) -> List[Dict[str, object]]:
+        """reference: trocr_ocr_processor.py:241-367.  Fragments that carry the window of a device page they were cut from
+        (``FragmentList`` from the MI355X box processor) are read where they are; anything else is packed and uploaded."""
         import torch
 
         results: List[Dict[str, object]] = []
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        on_device = getattr(src_images, "windows", None) is not None
         for start in range(0, len(src_images), self.batch_size):
-            batch = src_images[start:start + self.batch_size]
-            packed, descs = pack_fragments([f if np.ndim(f) == 3 else np.repeat(np.asarray(f)[:, :, None], 3, axis=2) for f in batch])
-            d_in = torch.from_numpy(packed).cuda()
-            hyps = self.model.generate_fragments(d_in.data_ptr(), descs, len(batch), swap_rb=True)   # fragments are BGR
+            stop = min(len(src_images), start + self.batch_size)
+            if on_device:
+                base, descs = src_images.device_descs(start, stop)
+                hyps = self.model.generate_fragments(base, descs, stop - start, swap_rb=True)              # fragments are BGR
+            else:
+                batch = src_images[start:stop]
+                packed, descs = pack_fragments([f if np.ndim(f) == 3 else np.repeat(np.asarray(f)[:, :, None], 3, axis=2)
+                                                for f in batch])
+                d_in = torch.from_numpy(packed).cuda()
+                hyps = self.model.generate_fragments(d_in.data_ptr(), descs, len(batch), swap_rb=True)
             for k, (tokens, score) in enumerate(hyps):
                 conf = round(math.exp(score), 6)                 # get_text: round(exp(score), 6), then round(score, 4)
                 text = self._text(tokens)

@@ -214,3 +214,51 @@ def test_mixed_dpi_pages_interleaved_through_ingest_and_engine(ctx):
         assert a == t and len(a) > 0, i
         assert np.allclose([w["confidence"] for w in alone["words"]], [w["confidence"] for w in together[i]["words"]], atol=2e-3)
     assert together[0]["meta"]["imageSize"]["width"] == 160 and together[2]["meta"]["imageSize"]["width"] == 320
+
+
+def test_engine_batched_path_equals_per_page_loop(ctx):
+    """MarieHipOcrEngine.extract batches pages through the detector and pools their fragments into one recognizer batch
+    (two contexts -> detector of batch k+1 overlaps the recognizer of batch k).  Every page's result must be what the
+    reference's per-page loop (ocr_engine.py:172-221) gives: refinement passes on, a framed small page, a blank page and two
+    page sizes in one call; fragments travel as device windows in the batched path and as host arrays in the loop."""
+    from marie_icr_amd._lib import Context
+    from marie_icr_amd.box_processor import PSMode
+    from marie_icr_amd.dit import default_config as dit_config
+    from marie_icr_amd.dit_box_processor import BoxProcessorUlimDit
+    from marie_icr_amd.fragments import FragmentList
+    from marie_icr_amd.ocr_engine import CoordinateFormat, MarieHipOcrEngine
+    from marie_icr_amd.trocr import TrOcrProcessor, default_config as trocr_config
+    from marie_icr_amd.weights import make_dit_state, make_image_u8, make_trocr_state
+
+    ctx2 = Context(0)
+    dcfg = dit_config(ctx.lib, "base")
+    dcfg.min_size_test, dcfg.max_size_test = 160, 400
+    enc, dec = (256, 2, 4), (256, 2, 4, 512)
+    tcfg = trocr_config(ctx.lib, "base")
+    tcfg.enc_dim, tcfg.enc_depth, tcfg.enc_heads = enc
+    tcfg.dec_dim, tcfg.dec_layers, tcfg.dec_heads, tcfg.dec_ffn = dec
+    tcfg.vocab, tcfg.max_positions, tcfg.max_len_b = 97, 32, 8
+    box = BoxProcessorUlimDit(cuda=True, state=make_dit_state(0), model="base", precision="f16", ctx=ctx, config=dcfg,
+                              refinement=True, det_batch=2)
+    rec = TrOcrProcessor(state=make_trocr_state(0, enc, dec, 97, 32), config=tcfg, precision="f16", ctx=ctx2, batch_size=64)
+    eng = MarieHipOcrEngine(box_processor=box, default_ocr_processor=rec)
+    eng.page_batch = 2
+    sizes = [(330, 255), (248, 192), (330, 255), (100, 120), (330, 255)]
+    frames = [make_image_u8(60 + i, 1, h, w)[0] for i, (h, w) in enumerate(sizes)]
+    frames.append(np.full((330, 255, 3), 255, np.uint8))                       # blank page: no boxes
+    got = eng.extract(frames, PSMode.SPARSE, CoordinateFormat.XYXY)
+    assert len(got) == len(frames)
+    for i, page in enumerate(frames):
+        rects, frags, numbers, _, line_boxes = box.extract_bounding_boxes("q", "k", page, PSMode.SPARSE)
+        assert isinstance(frags, FragmentList) and (frags.windows is not None) == (i != 3)   # the framed page has host fragments only
+        ref, _ = rec.recognize("q", "k", page, rects, list(frags), numbers)                   # plain list: packed + uploaded
+        ref = MarieHipOcrEngine._finish_page(ref, i, numbers, line_boxes, CoordinateFormat.XYXY)
+        a = [(tuple(int(v) for v in w["box"]), w["text"], int(w["line"]), w["id"], w["word_index"]) for w in ref["words"]]
+        t = [(tuple(int(v) for v in w["box"]), w["text"], int(w["line"]), w["id"], w["word_index"]) for w in got[i]["words"]]
+        assert a == t, i
+        assert np.allclose([w["confidence"] for w in ref["words"]], [w["confidence"] for w in got[i]["words"]], atol=2e-3)
+        assert [(ln["line"], ln["text"], ln["wordids"]) for ln in ref["lines"]] == \
+               [(ln["line"], ln["text"], ln["wordids"]) for ln in got[i]["lines"]]
+        assert got[i]["meta"]["page"] == i and got[i]["meta"]["format"] == "xyxy"
+        assert (len(a) > 0) == (i != 5)
+    ctx2.close()
