@@ -28,14 +28,26 @@ random weights their number is arbitrary, so that mode is the secondary number).
 ``--workload crnn`` = BASELINE configs[1]: the CRNN recognizer alone on 1024 pre-cropped 32x256 lines per GPU.
 
 Multi-GPU: pages are independent, so each rank owns its own pages — weak scaling, no data-path
-collective.  Rank 0 packs the weights and the packed arenas are broadcast once over RCCL/xGMI at start-up; the timed
+collective.  ``python bench.py --gpus N`` (N > 1) with no launcher around it starts the N ranks itself (a child
+``torch.distributed.run`` before anything touches the GPU); under a launcher WORLD_SIZE must equal ``--gpus`` or the run
+exits non-zero.  Rank 0 packs the weights and the packed arenas are broadcast once over RCCL/xGMI at start-up; the timed
 region is bracketed by barrier + synchronize and the maximum over ranks is reported.
 
-Rank 0 prints ONE JSON line.  ``roofline`` covers the dominant kernel (conv_igemm, MFMA-bound): algorithmic FLOPs of
-all its launches in a step (mhip_craft_kernel_flops + mhip_crnn_kernel_flops: real channel counts, 2*MAC) divided by
-its summed device time, measured live with HIP events on the launch stream inside the timed steps.  ``cpu_baseline``
-times the CPU oracle (torch CPU ops — what the reference executes on a CPU host — plus the reference's numpy
-post-processing restated) on rank 0's host cores on a bounded sample of the same workload.
+Secondary legs of the default workload, all in the same JSON line (never ``value``):
+  ``stream``      BASELINE configs[3] — a fixed stream (2048 pages when N > 1) sharded round-robin over the ranks
+                  (``marie_icr_amd.dist.shard_indices``), boxes-per-page and token ids gathered in page order
+                  (``gather_in_order``); strong scaling; ``result_checksum`` is the same for every N.
+  ``mixed_dpi``   BASELINE configs[4] — 150/200/300-DPI pages interleaved, chunks pulled from a host work queue, pages
+                  bucketed by size, crops pooled.
+  ``engine_api``  the same models behind ``MarieHipOcrEngine.extract`` (host frames in, dictionaries out).
+  ``det_passes_3``, ``pcie_inclusive``, ``parity`` (GPU vs oracle on the cpu_baseline sample).
+
+Rank 0 prints ONE JSON line.  ``roofline`` covers the dominant kernel (conv_igemm, MFMA-bound): algorithmic FLOPs of all
+its launches in a step (2*MAC, real channel counts, accumulated by the launcher: mhip_profile_flops) divided by their
+summed device time, measured live with HIP events on the launch streams in one more step run exactly like the timed ones
+(``frac``: in situ, two streams) and once with the detector and the recognizer alone (``isolated``); ``by_tile`` splits
+both by tile shape.  ``cpu_baseline`` times the CPU oracle (torch CPU ops — what the reference executes on a CPU host —
+plus the reference's numpy post-processing restated) on rank 0's host cores on a bounded sample of the same workload.
 """
 from __future__ import annotations
 
@@ -121,55 +133,142 @@ def cpu_baseline_pages(craft_state, crnn_state, charset, img_w, n_lines):
                       f"({len(rects)} boxes; torch CPU forward + the reference's per-component numpy loop), "
                       f"{n_lines} line crops + recognizer {t2 - t1:.2f} s"}
 
-def cpu_baseline_dit_trocr(dit_state, trocr_state, trocr_dims, decode_len, n_lines):
+def host_cores_physical():
+    """(physical cores the process may use, logical CPUs it may use): lscpu -p lists one row per logical CPU with its core
+    and socket; unique (core, socket) pairs among the CPUs in our affinity mask are physical cores."""
+    import subprocess
+
+    try:
+        aff = os.sched_getaffinity(0)
+    except AttributeError:
+        aff = set(range(os.cpu_count() or 1))
+    try:
+        rows = subprocess.run(["lscpu", "-p=cpu,core,socket"], capture_output=True, text=True, timeout=10).stdout.splitlines()
+        cores = {tuple(r.split(",")[1:3]) for r in rows if r and not r.startswith("#") and int(r.split(",")[0]) in aff}
+        phys = len(cores) or len(aff)
+    except Exception:
+        phys = len(aff)
+    return max(1, phys), max(1, len(aff))
+
+
+def _iou_match(ref, got, bar):
+    if len(ref) == 0 or len(got) == 0:
+        return 0.0
+    a, b = np.asarray(ref, np.float64), np.asarray(got, np.float64)
+    x1 = np.maximum(a[:, None, 0], b[None, :, 0]); y1 = np.maximum(a[:, None, 1], b[None, :, 1])
+    x2 = np.minimum(a[:, None, 2], b[None, :, 2]); y2 = np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    iou = inter / (aa[:, None] + ab[None, :] - inter + 1e-12)
+    return float((iou.max(axis=1) >= bar).mean())
+
+
+def cpu_baseline_dit_trocr(dit_state, trocr_state, trocr_dims, decode_len, n_lines, det, rec, precision):
     """The CPU oracle pipeline on a bounded sample (rank 0, N=1 only): one full 2550x3300 page through the DiT-base
-    detector (one pass) and 3 line crops through TrOCR-base, beam 3; the recognizer time is scaled to n_lines crops."""
+    detector (one pass) and 4 line crops through TrOCR-base, beam 3; the recognizer time is scaled to n_lines crops.
+    The same page and crops also go through the GPU models that were just timed, and the two outputs are compared
+    (``parity``; the assertions live in tests/test_fullsize_gpu.py)."""
     import torch
 
     from marie_icr_amd.weights import make_page_bgr, page_line_boxes
     from oracle.dit_torch import TorchDitOracle
     from oracle.trocr_torch import TorchTrocrOracle, preprocess_fragments
 
-    cores = host_cores()
-    torch.set_num_threads(cores)
+    phys, logical = host_cores_physical()
+    torch.set_num_threads(phys)
     page = make_page_bgr(999, PAGE_H, PAGE_W, n_lines=n_lines)
     lines = page_line_boxes(PAGE_H, PAGE_W, n_lines)
-    det = TorchDitOracle(dit_state)
+    odet = TorchDitOracle(dit_state)
+    odet.detect(page[:660, :510].copy())                     # warm-up (thread pool, allocator) on a small window
     t0 = time.perf_counter()
-    boxes, _ = det.detect(page)
+    boxes, scores = odet.detect(page)
     t1 = time.perf_counter()
     enc, dec, vocab = trocr_dims
-    rec = TorchTrocrOracle(trocr_state, enc[2], dec[2], beam=3, max_len_b=decode_len)
-    k = 3
-    frags = [page[y:y + h + 1, x:x + w + 1] for x, y, w, h in lines[:k].tolist()]
+    orec = TorchTrocrOracle(trocr_state, enc[2], dec[2], beam=3, max_len_b=decode_len)
+    k = 4
+    frags = [page[y:y + h + 1, x:x + w + 1] for x, y, w, h in lines[[0, 7, 19, 33]].tolist()]
+    crops = preprocess_fragments(frags)
     t2 = time.perf_counter()
-    rec.generate(preprocess_fragments(frags))
+    ref = orec.generate(crops)
     t3 = time.perf_counter()
     per_page = (t1 - t0) + (t3 - t2) / k * n_lines
-    return {"value": 1.0 / per_page, "unit": "pages/s", "cores": cores, "kind": "port",
+    base = {"value": 1.0 / per_page, "unit": "pages/s", "cores": phys, "logical_cpus": logical, "kind": "port",
             "sample": f"1 of the same seeded {PAGE_W}x{PAGE_H} pages through the detector oracle ({t1 - t0:.1f} s, "
-                      f"{len(boxes)} boxes, torch CPU fp32) + {k} of its {n_lines} line crops through the TrOCR oracle "
-                      f"({(t3 - t2) / k:.2f} s/crop, beam 3, {decode_len}+1 steps), recognizer time scaled to {n_lines} crops"}
+                      f"{len(boxes)} boxes, torch CPU fp32, {phys} threads = physical cores of the affinity mask) + {k} of "
+                      f"its {n_lines} line crops through the TrOCR oracle ({(t3 - t2) / k:.2f} s/crop, beam 3, "
+                      f"{decode_len}+1 steps), recognizer time scaled to {n_lines} crops"}
+    # ---- the GPU path on the same inputs ----
+    (gb, gs), = det.detect_host(page[None])
+    got = rec.generate_host(crops)
+    equal = [bool(len(g[0]) == len(r[0]) and np.array_equal(g[0], r[0])) for g, r in zip(got, ref)]
+    own = orec.score_tokens(crops, [g[0] for g in got])
+    parity = {"dtype": precision, "page": "seed 999",
+              "boxes": {"oracle": int(len(boxes)), "gpu": int(len(gb)),
+                        "matched_iou_0.999": _iou_match(boxes, gb, 0.999), "matched_iou_0.99": _iou_match(boxes, gb, 0.99),
+                        "matched_iou_0.9": _iou_match(boxes, gb, 0.9), "matched_iou_0.5": _iou_match(boxes, gb, 0.5)},
+              "trocr": {"crops": k, "hypotheses_token_equal": int(sum(equal)),
+                        "max_abs_score_diff_where_equal": max([abs(g[1] - r[1]) for g, r, e in zip(got, ref, equal) if e] or [0.0]),
+                        "oracle_best_minus_oracle_score_of_gpu_hypothesis": [float(r[1] - s_) for r, s_ in zip(ref, own)]},
+              "note": "f16 operands re-order near-tied discrete choices of a random-weight model; the fp32 bars (911/911 boxes "
+                      "at IoU >= 0.999, tokens exact) are asserted in tests/test_fullsize_gpu.py"}
+    return base, parity
 
 
 def _pmc_traffic(config):
-    """profiles/r01/p_pmc_traffic.json (rocprofv3 --pmc passes folded by tools/pmc_traffic.py) if it was taken on `config`."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "p_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except (OSError, ValueError):
-        return None
-    return d if d.get("config") == config else None
+    """profiles/r02/pmc_traffic.json (rocprofv3 --pmc passes folded by tools/pmc_traffic.py) if it was taken on `config`."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json" if rnd == "r02" else "p_pmc_traffic.json")
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("config") == config:
+            d["source"] = os.path.relpath(path, ROOT)
+            return d
+    return None
+
+
+MIXED_DPI_SIZES = ((1650, 1275), (2200, 1700), (3300, 2550))      # 150 / 200 / 300 DPI letter pages, (h, w)
+IGEMM_VARIANTS = ("conv_igemm<64>", "conv_igemm<128>", "conv_igemm<256>", "conv_igemm<1128>", "conv3x3_patch")
+
+
+class _WorkQueue:
+    """Host work queue shared by the ranks of one node (BASELINE configs[4]): an atomic counter in torch.distributed's
+    store — ``next()`` hands out chunk ids 0, 1, 2 ... to whichever rank asks first."""
+
+    def __init__(self, dist, name):
+        self.local = 0
+        self.store = None
+        self.key = name
+        if dist is not None:
+            from torch.distributed import distributed_c10d as c10d
+
+            self.store = c10d._get_default_store()
+
+    def next(self):
+        if self.store is None:
+            self.local += 1
+            return self.local - 1
+        return int(self.store.add(self.key, 1)) - 1
+
+
+def _checksum(records):
+    """Order-sensitive checksum of gathered results [(page index, n boxes, token lists)]."""
+    acc = 0
+    for i, (pi, nb, toks) in enumerate(records):
+        t = sum((j + 1) * int(sum(int(v) for v in tk)) for j, tk in enumerate(toks))
+        acc = (acc * 1000003 + (i + 1) * (pi + 1) * 7919 + nb * 104729 + t) % (1 << 61)
+    return acc
 
 
 def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
-    """BASELINE configs[2]: DiT-base detector + TrOCR-base recognizer, full pages, one GPU per rank."""
-    import ctypes as C
+    """BASELINE configs[2] (default), configs[3] (--stream-pages) and configs[4] (mixed-DPI leg): DiT-base detector +
+    TrOCR-base recognizer, full pages, one GPU per rank."""
     import threading
 
     from marie_icr_amd._lib import Context, CropDesc
-    from marie_icr_amd.dist import arenas_checksum, broadcast_arenas
+    from marie_icr_amd.dist import arenas_checksum, broadcast_arenas, gather_in_order, shard_indices
     from marie_icr_amd.dit import DitModel
     from marie_icr_amd.trocr import TrocrModel, default_config as trocr_config
     from marie_icr_amd.weights import make_dit_state, make_page_bgr, make_trocr_state, page_line_boxes
@@ -183,8 +282,9 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
     tcfg.max_len_b = args.decode_len
     dims = ((tcfg.enc_dim, tcfg.enc_depth, tcfg.enc_heads), (tcfg.dec_dim, tcfg.dec_layers, tcfg.dec_heads, tcfg.dec_ffn),
             tcfg.vocab)
-    dit_state = make_dit_state(0, args.model) if rank == 0 else None
-    trocr_state = make_trocr_state(0, dims[0], dims[1], dims[2], tcfg.max_positions) if rank == 0 else None
+    need_state = rank == 0
+    dit_state = make_dit_state(0, args.model) if need_state else None
+    trocr_state = make_trocr_state(0, dims[0], dims[1], dims[2], tcfg.max_positions) if need_state else None
     det = DitModel(ctxs[0], dit_state, model=args.model, precision=prec)
     rec = TrocrModel(ctxs[1], trocr_state, tcfg, prec)
     if world > 1:      # rank 0 packed the weights; everyone else receives the packed arenas over RCCL / xGMI
@@ -197,37 +297,54 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
                 dist.all_gather_object(sums, arenas_checksum(m, c))
                 if len(set(sums)) != 1:
                     raise SystemExit(f"rank {rank}: weight arenas differ across ranks after the broadcast: {sums}")
-    host_pages = np.stack([make_page_bgr(1000 + rank * 97 + i, PAGE_H, PAGE_W, n_lines=LINES_PER_PAGE) for i in range(min(P, 4))])
-    pages = torch.from_numpy(host_pages[np.arange(P) % len(host_pages)]).cuda()     # [P][H][W][3] in HBM
+    n_pool = min(P, 4)
+    host_pages = np.stack([make_page_bgr(1000 + rank * 97 + i, PAGE_H, PAGE_W, n_lines=LINES_PER_PAGE) for i in range(n_pool)])
+    pages = torch.from_numpy(host_pages[np.arange(P) % n_pool]).cuda()     # [P][H][W][3] in HBM
     page_bytes = PAGE_H * PAGE_W * 3
     gt = page_line_boxes(PAGE_H, PAGE_W, LINES_PER_PAGE)
-    n_crops = P * LINES_PER_PAGE
-    descs = (CropDesc * n_crops)()
-    i = 0
-    for pi in range(P):
-        for x, y, w, h in gt.tolist():
-            descs[i] = CropDesc(pi * page_bytes + (y * PAGE_W + x) * 3, h + 1, w + 1, PAGE_W * 3, 3)
-            i += 1
+    def make_descs(slots):
+        """crop windows of the generator's line boxes for pages sitting in slots `slots` of a packed page buffer"""
+        d = (CropDesc * (len(slots) * LINES_PER_PAGE))()
+        i = 0
+        for sl in slots:
+            for x, y, w, h in gt.tolist():
+                d[i] = CropDesc(sl * page_bytes + (y * PAGE_W + x) * 3, h + 1, w + 1, PAGE_W * 3, 3)
+                i += 1
+        return d
+
     stats = {"boxes": 0}
     last = [None]
-
-    base = [pages.data_ptr()]        # device address of the P packed pages the two halves read
+    last_det = [None]
+    det_passes = [args.det_passes]
+    # what a step works on: device address of a packed page buffer, the slots of the step's pages in it, their crop windows
+    cur = {"base": pages.data_ptr(), "slots": list(range(P)), "descs": make_descs(range(P))}
 
     def detect_all():
         nb = 0
-        for _ in range(args.det_passes):
-            for s0 in range(0, P, DB):
-                ptrs = [base[0] + pi * page_bytes for pi in range(s0, min(P, s0 + DB))]
+        per_page = []
+        slots = cur["slots"]
+        for pz in range(det_passes[0]):
+            for s0 in range(0, len(slots), DB):
+                ptrs = [cur["base"] + sl * page_bytes for sl in slots[s0:s0 + DB]]
                 for boxes, _scores in det.detect_device(ptrs, PAGE_H, PAGE_W):
                     nb += len(boxes)
-        stats["boxes"] += nb // args.det_passes
+                    if pz == 0:
+                        per_page.append(len(boxes))
+        stats["boxes"] += nb // det_passes[0]
+        last_det[0] = per_page
 
     def recognize_all():
-        last[0] = rec.generate_fragments(base[0], descs, n_crops, swap_rb=True)
+        last[0] = rec.generate_fragments(cur["base"], cur["descs"], len(cur["slots"]) * LINES_PER_PAGE, swap_rb=True)
 
-    def run(k):
+    def run(k, serial=False):
         # the detector and the recognizer of a step work on the same pages but do not depend on each other here (the
         # recognizer consumes ground-truth boxes), so they run as two host threads on two streams
+        if serial:
+            for _ in range(k):
+                detect_all()
+                torch.cuda.synchronize()
+                recognize_all()
+            return
         def loop(fn):
             for _ in range(k):
                 fn()
@@ -243,29 +360,31 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(max(1, args.warmup))
+    run(max(1, args.warmup), args.serial)
     fence()
     stats["boxes"] = 0
     fence()
     t0 = time.perf_counter()
-    run(args.steps)
+    run(args.steps, args.serial)
     fence()
     dt = time.perf_counter() - t0
     boxes_pp = stats["boxes"] / (args.steps * P)
 
-    prof = None
-    if not args.no_kernel_timing:      # one more step, the two halves one after the other, HIP events per kernel
+    def profiled(serial):
         for c in ctxs:
             c.profile_reset()
             c.profile_enable(True)
         tA = time.perf_counter()
-        detect_all()
-        torch.cuda.synchronize()
-        tB = time.perf_counter()
-        recognize_all()
+        if serial:
+            detect_all()
+            torch.cuda.synchronize()
+            tB = time.perf_counter()
+            recognize_all()
+        else:
+            run(1)
+            tB = tA
         fence()
         tC = time.perf_counter()
-        alone_ms = {"detector_ms_per_step_alone": 1e3 * (tB - tA), "recognizer_ms_per_step_alone": 1e3 * (tC - tB)}
         prof = {}
         for c in ctxs:
             for name, v in c.profile_read().items():
@@ -273,6 +392,25 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
                 for kk in acc:
                     acc[kk] += v[kk]
             c.profile_enable(False)
+        return prof, 1e3 * (tB - tA), 1e3 * (tC - tB)
+
+    prof = prof_iso = None
+    if not args.no_kernel_timing:      # two more steps with HIP events around every kernel: as timed (two streams), then serial
+        prof, _, wall_ms = profiled(args.serial)
+        prof_iso, det_ms, rec_ms = profiled(True)
+        alone_ms = {"detector_ms_per_step_alone": det_ms, "recognizer_ms_per_step_alone": rec_ms}
+    # ---- secondary figures (N = 1 only, after the timed region) ----------------------------------------------------------
+    extra = {}
+    if world == 1 and not args.no_secondary:
+        det_passes[0] = 3                      # worst case of the reference's default refinement loop (3 detector forwards)
+        run(1)
+        fence()
+        t1 = time.perf_counter()
+        run(2)
+        fence()
+        extra["det_passes_3"] = {"value": 2 * P / (time.perf_counter() - t1), "unit": "pages/s",
+                                 "what": "same step with three detector forwards per page (bbox_refinement=True worst case)"}
+        det_passes[0] = args.det_passes
     pcie = None
     if world == 1 and args.host_steps > 0:
         # The same step with the pages arriving in (pinned) host memory: marie_icr_amd.ingest.PageFeeder copies step
@@ -288,18 +426,68 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
             if i == 1:                 # step 0 warms the pinned buffers and the copy stream up
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-            base[0] = ptr
+            cur["base"] = ptr
             run(1)
         torch.cuda.synchronize()
         dth = time.perf_counter() - t1
-        base[0] = pages.data_ptr()
+        cur["base"] = pages.data_ptr()
         pcie = {"value": P * hs / dth, "unit": "pages/s", "steps": hs, "ms_per_step": 1e3 * dth / hs,
                 "h2d_gb_per_step": P * page_bytes / 1e9,
                 "how": "pages in pinned host memory, double-buffered H2D on a copy stream under the previous step's kernels"}
+        del feeder
+
+    # ---- BASELINE configs[3]: a fixed stream of pages sharded over the ranks, results gathered in page order -------------
+    stream = None
+    total = args.stream_pages if args.stream_pages >= 0 else (2048 if world > 1 else 0)
+    if total > 0:
+        mine = shard_indices(total, rank, world)          # rank r owns pages r, r + world, ...
+        # page i of the stream = seeded page i % 4, the same on every rank (so the gathered result does not depend on N)
+        spool = torch.from_numpy(np.stack([make_page_bgr(2000 + i, PAGE_H, PAGE_W, n_lines=LINES_PER_PAGE)
+                                           for i in range(4)])).cuda()
+        saved = dict(cur)
+        desc_cache = {}
+        fence()
+        t1 = time.perf_counter()
+        local = []
+        for s0 in range(0, len(mine), P):
+            ids = mine[s0:s0 + P]
+            slots = [pi % 4 for pi in ids]
+            key = tuple(slots)
+            if key not in desc_cache:
+                desc_cache[key] = make_descs(slots)
+            cur.update({"base": spool.data_ptr(), "slots": slots, "descs": desc_cache[key]})
+            run(1)
+            hyps = last[0]
+            for j, pi in enumerate(ids):
+                toks = [hyps[j * LINES_PER_PAGE + c][0].tolist() for c in range(LINES_PER_PAGE)]
+                local.append((pi, int(last_det[0][j]), toks))
+        cur.update(saved)
+        allrec = gather_in_order(local, total, dist)       # all_gather_object: variable-length records, page order
+        fence()
+        ds = time.perf_counter() - t1
+        if dist is not None:
+            tm = torch.tensor([ds], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            ds = float(tm.item())
+        assert [r[0] for r in allrec] == list(range(total))
+        stream = {"config": "BASELINE configs[3]: fixed stream, static round-robin shard (marie_icr_amd.dist.shard_indices), "
+                            "boxes-per-page + token ids gathered in page order (gather_in_order)",
+                  "pages": total, "seconds": ds, "value": total / ds, "unit": "pages/s", "scaling": "strong",
+                  "pages_per_rank": len(mine), "steps_per_rank": (len(mine) + P - 1) // P,
+                  "result_checksum": _checksum(allrec)}
+
+    # ---- BASELINE configs[4]: mixed-DPI stream, host work queue, pages bucketed by size, crops pooled ---------------------
+    mixed = None
+    if not args.no_mixed_dpi:
+        mixed = run_mixed_dpi(args, torch, dist, rank, world, det, rec, ctxs, streams, fence)
+
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    engine = None
+    if world == 1 and not args.no_secondary:
+        engine = run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt)
     if rank != 0:
         return
     rate = world * P * args.steps / dt
@@ -310,24 +498,37 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[2]: full detect->crop->recognize, {P} synthetic {PAGE_W}x{PAGE_H}x3 u8 pages per "
-                        f"GPU per step resident in HBM; DiT-{args.model} Mask R-CNN detector (resize to {nh}x{nw}, 1 pass, "
-                        f"{args.det_batch} pages per forward) + TrOCR-base recognizer on the generator's {LINES_PER_PAGE} "
-                        f"ground-truth line boxes per page (fixed work), beam 3, {args.decode_len}+1 decoder steps; seeded "
-                        f"random weights",
+                        f"GPU per step resident in HBM; DiT-{args.model} Mask R-CNN detector (resize to {nh}x{nw}, "
+                        f"{args.det_passes} pass, {args.det_batch} pages per forward) + TrOCR-base recognizer on the "
+                        f"generator's {LINES_PER_PAGE} ground-truth line boxes per page (fixed work), beam 3, "
+                        f"{args.decode_len}+1 decoder steps; seeded random weights; f16 operands with fp32 accumulation is the "
+                        f"16-bit mode of this build (configs[2] says bf16: same width; the reference's GPU path is .half())"
+                        + ("; detector and recognizer run one after the other (--serial)" if args.serial else ""),
             "pages_per_gpu_per_step": P, "crops_per_page": LINES_PER_PAGE, "detector_boxes_per_page": boxes_pp,
             "parallelism": f"dp{world} (independent pages); detector and recognizer on two streams per GPU",
         },
     }
     if prof is not None:
-        k = prof["conv_igemm"]
-        ach = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
         peak = PEAK_MFMA_TFLOPS_F16 if args.precision == "f16" else PEAK_MFMA_TFLOPS_F32
+
+        def tf(k):
+            return k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
+
+        k, ki = prof["conv_igemm"], prof_iso["conv_igemm"]
+        ach = tf(k)
         out["roofline"] = {
             "bound": "mfma", "kernel": "conv_igemm", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "traffic": None, "launches_per_step": k["launches"], "avg_launch_ms": k["total_ms"] / max(k["launches"], 1),
-            "algorithmic_gflop_per_step": k["flops"] / 1e9,
-            "measured": "HIP events on the launch streams, detector then recognizer alone, same step right after the "
-                        "timed region; FLOPs = 2*MAC of every launch (mhip_profile_flops)",
+            "algorithmic_gflop_per_step": k["flops"] / 1e9, "algorithmic_gflop_per_launch": k["flops"] / 1e9 / max(k["launches"], 1),
+            "measured": "HIP events on the launch streams around every conv_igemm launch of one more step run exactly as the "
+                        "timed steps (detector and recognizer concurrently on two streams: in situ); FLOPs = 2*MAC of every "
+                        "launch (mhip_profile_flops).  profiles/r02/*_kernel_stats.csv is rocprofv3 --kernel-trace --stats of "
+                        "this command: sum its conv_igemm_kernel + conv3x3_patch_kernel rows",
+            "isolated": {"achieved": tf(ki), "frac": tf(ki) / peak, "avg_launch_ms": ki["total_ms"] / max(ki["launches"], 1),
+                         "measured": "same step, detector then recognizer alone (nothing else on the GPU); rocprofv3 of "
+                                     "`bench.py --serial` reproduces it"},
+            "by_tile": {n: {"launches": prof[n]["launches"], "gflop": prof[n]["flops"] / 1e9, "ms": prof[n]["total_ms"],
+                            "tflops": tf(prof[n]), "tflops_isolated": tf(prof_iso[n])} for n in IGEMM_VARIANTS if prof[n]["launches"]},
         }
         # HBM-side bytes per launch: PMC counters cannot be read from inside this process, so the committed result of
         # the rocprofv3 --pmc passes over this same configuration is reported (null for any other configuration)
@@ -335,21 +536,198 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
                             "model": args.model, "det_passes": args.det_passes, "precision": args.precision})
         if pmc is not None and "conv_igemm" in pmc["kernels"]:
             out["roofline"]["traffic"] = pmc["kernels"]["conv_igemm"]["bytes_per_launch"]
-            out["roofline"]["traffic_unit"] = ("bytes per launch, HBM side (FETCH_SIZE x 2 + WRITE_SIZE; "
-                                               "profiles/r01/p_pmc_traffic.json)")
-        a = prof["attn_flash"]
-        out["roofline_attention"] = {"kernel": "attn_flash", "bound": "mfma",
-                                     "achieved": a["flops"] / (a["total_ms"] * 1e-3) / 1e12 if a["total_ms"] > 0 else 0.0,
+            out["roofline"]["traffic_unit"] = f"bytes per launch, HBM side (FETCH_SIZE x 2 + WRITE_SIZE; {pmc['source']})"
+        a, ai = prof["attn_flash"], prof_iso["attn_flash"]
+        out["roofline_attention"] = {"kernel": "attn_flash", "bound": "mfma", "achieved": tf(a), "isolated": tf(ai),
                                      "peak": peak, "unit": "TFLOP/s", "algorithmic_gflop_per_step": a["flops"] / 1e9}
-        out["kernels_ms_per_step"] = {n: v["total_ms"] for n, v in prof.items() if v["launches"]}
-        out["kernel_ms_over_wall_ms"] = sum(out["kernels_ms_per_step"].values()) / (1e3 * dt / args.steps)
+        agg = {n: v["total_ms"] for n, v in prof.items() if v["launches"] and n not in IGEMM_VARIANTS}
+        out["kernels_ms_per_step"] = agg
+        out["kernels_ms_per_step_isolated"] = {n: v["total_ms"] for n, v in prof_iso.items() if v["launches"] and n not in IGEMM_VARIANTS}
+        out["kernel_ms_over_wall_ms"] = sum(agg.values()) / (1e3 * dt / args.steps)
         out.update(alone_ms)
+    out.update(extra)
     if pcie is not None:
         out["pcie_inclusive"] = pcie
+    if stream is not None:
+        out["stream"] = stream
+    if mixed is not None:
+        out["mixed_dpi"] = mixed
+    if engine is not None:
+        out["engine_api"] = engine
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_dit_trocr(dit_state, trocr_state, dims, args.decode_len, LINES_PER_PAGE)
+        out["cpu_baseline"], out["parity"] = cpu_baseline_dit_trocr(dit_state, trocr_state, dims, args.decode_len,
+                                                                    LINES_PER_PAGE, det, rec, args.precision)
     out["sample_output"] = [[int(t) for t in last[0][0][0]], last[0][0][1]] if last[0] else None
     print(json.dumps(out), flush=True)
+
+
+def run_mixed_dpi(args, torch, dist, rank, world, det, rec, ctxs, streams, fence):
+    """BASELINE configs[4]: pages scanned at 150 / 200 / 300 DPI interleaved (page i has size i % 3).  Ranks pull chunks of
+    24 consecutive pages from a host work queue (whoever is free takes the next chunk: big and small pages cost different
+    time), bucket the chunk's pages by size for the detector (8 same-size pages per forward) and pool the line crops of the
+    whole chunk into one recognizer batch (every crop is resized to 384 x 384 on the device whatever its source DPI)."""
+    import threading
+
+    from marie_icr_amd._lib import CropDesc
+    from marie_icr_amd.dist import gather_in_order
+    from marie_icr_amd.weights import make_page_bgr, page_line_boxes
+
+    CH = 24
+    total = max(CH, (args.mixed_pages // CH) * CH) * world
+    n_chunks = total // CH
+    pool, gts = [], []
+    for k, (h, w) in enumerate(MIXED_DPI_SIZES):            # two distinct pages per size, resident in HBM
+        hp = np.stack([make_page_bgr(3000 + 10 * k + j, h, w, n_lines=LINES_PER_PAGE) for j in range(2)])
+        pool.append(torch.from_numpy(hp).cuda())
+        gts.append(page_line_boxes(h, w, LINES_PER_PAGE))
+    base = min(p.data_ptr() for p in pool)
+
+    def page_ptr(i):
+        k = i % 3
+        return pool[k].data_ptr() + ((i // 3) % 2) * pool[k][0].numel(), k
+
+    def chunk_inputs(c):
+        ids = list(range(c * CH, (c + 1) * CH))
+        buckets = {0: [], 1: [], 2: []}
+        descs = (CropDesc * (CH * LINES_PER_PAGE))()
+        n = 0
+        for i in ids:
+            ptr, k = page_ptr(i)
+            buckets[k].append(ptr)
+            h, w = MIXED_DPI_SIZES[k]
+            for x, y, bw, bh in gts[k].tolist():
+                descs[n] = CropDesc(ptr - base + (y * w + x) * 3, bh + 1, bw + 1, w * 3, 3)
+                n += 1
+        return ids, buckets, descs, n
+
+    def process(c):
+        ids, buckets, descs, n = chunk_inputs(c)
+        res = {}
+
+        def detect():
+            counts = {}
+            for k, ptrs in buckets.items():
+                h, w = MIXED_DPI_SIZES[k]
+                out = []
+                for s0 in range(0, len(ptrs), args.det_batch):
+                    out += [len(b) for b, _ in det.detect_device(ptrs[s0:s0 + args.det_batch], h, w)]
+                counts[k] = out
+            res["det"] = counts
+
+        def recognize():
+            res["hyp"] = rec.generate_fragments(base, descs, n, swap_rb=True)
+
+        ths = [threading.Thread(target=f) for f in (detect, recognize)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        seen = {0: 0, 1: 0, 2: 0}
+        recs = []
+        for j, i in enumerate(ids):
+            k = i % 3
+            nb = res["det"][k][seen[k]]
+            seen[k] += 1
+            recs.append((i, int(nb), [res["hyp"][j * LINES_PER_PAGE + c_][0].tolist() for c_ in range(LINES_PER_PAGE)]))
+        return recs
+
+    process(0)                                              # warm-up: three page geometries, one chunk-sized recognizer batch
+    fence()
+    q = _WorkQueue(dist, "mixed_dpi_next")
+    t0 = time.perf_counter()
+    local, mine = [], []
+    while True:
+        c = q.next()
+        if c >= n_chunks:
+            break
+        mine.append(c)
+        local.extend(process(c))
+    if dist is not None:
+        parts = [None] * world
+        dist.all_gather_object(parts, local)
+        allrec = sorted((r for p_ in parts for r in p_), key=lambda r: r[0])
+    else:
+        allrec = local
+    fence()
+    ds = time.perf_counter() - t0
+    if dist is not None:
+        tm = torch.tensor([ds], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ds = float(tm.item())
+    assert [r[0] for r in allrec] == list(range(total)), "mixed-DPI gather lost or duplicated pages"
+    if rank != 0:
+        return None
+    return {"config": "BASELINE configs[4]: 150/200/300-DPI pages interleaved (i % 3), chunks of 24 pages pulled from a host "
+                      "work queue (torch.distributed store counter), pages bucketed by size for the detector, line crops of a "
+                      "chunk pooled into one recognizer batch; f16", "pages": total, "seconds": ds, "value": total / ds,
+            "unit": "pages/s", "scaling": "strong", "chunks_this_rank": len(mine), "sizes_hw": [list(s) for s in MIXED_DPI_SIZES],
+            "result_checksum": _checksum(allrec)}
+
+
+def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
+    """The same models behind the drop-in surface: ``MarieHipOcrEngine.extract(frames)`` with host frames in, result
+    dictionaries out — H2D copy, detector, host geometry (merge_boxes, aspect filter, lines_from_bboxes, find_line_numbers,
+    sort), fragment windows, recognizer, ``OcrProcessor.recognize`` bookkeeping and token -> text all inside the timed call."""
+    from marie_icr_amd.box_processor import PSMode
+    from marie_icr_amd.dit_box_processor import BoxProcessorUlimDit
+    from marie_icr_amd.ocr_engine import CoordinateFormat, MarieHipOcrEngine
+    from marie_icr_amd.trocr import TrOcrProcessor
+
+    P = args.pages
+    frames = [host_pages[i % len(host_pages)] for i in range(P)]
+    gt_xyxy = np.stack([gt[:, 0], gt[:, 1], gt[:, 0] + gt[:, 2] + 1, gt[:, 1] + gt[:, 3] + 1], 1).astype(np.float32)
+
+    def make_box(fixed_lines, refinement):
+        bp = BoxProcessorUlimDit(cuda=True, refinement=refinement, dit_model=det, det_batch=args.det_batch)
+        if fixed_lines:
+            real = bp._detect_batch
+
+            def fixed(page_devs, shape):
+                real(page_devs, shape)                            # the detector runs in full; its (random-weight) boxes are dropped
+                return [(gt_xyxy.copy(), np.ones(len(gt_xyxy), np.float32)) for _ in page_devs]
+            bp._detect_batch = fixed
+        return bp
+
+    tp = TrOcrProcessor(trocr_model=rec, batch_size=P * LINES_PER_PAGE)
+    out = {}
+    for name, fixed, refine, n_pages in (("fixed_lines", True, False, P), ("detector_driven", False, False, min(P, 8)),
+                                         ("detector_driven_refinement", False, True, min(P, 8))):
+        eng = MarieHipOcrEngine(box_processor=make_box(fixed, refine), default_ocr_processor=tp)
+        eng.page_batch = P
+        fr = frames[:n_pages]
+        reps = 2 if fixed else 1
+        if fixed:
+            eng.extract(fr, PSMode.SPARSE, CoordinateFormat.XYXY)     # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = eng.extract(fr, PSMode.SPARSE, CoordinateFormat.XYXY)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        words = sum(len(r["words"]) for r in res) / len(res)
+        out[name] = {"value": reps * n_pages / dt, "unit": "pages/s", "pages_per_call": n_pages, "words_per_page": words,
+                     "lines_per_page": sum(len(r["lines"]) for r in res) / len(res)}
+    out["what"] = ("MarieHipOcrEngine.extract(frames) end to end, host numpy frames in (H2D inside), result dictionaries out; "
+                   "fixed_lines: the detector runs in full but the generator's 40 line boxes go on (the headline's fixed work, "
+                   "bbox_refinement=False); detector_driven: whatever the random-weight detector emits becomes a crop "
+                   "(SURVEY 8d B); _refinement: the reference's default 3-pass loop")
+    return out
+
+
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N ranks (one per GPU) under torch.distributed.run and hand
+    back its exit code.  Runs BEFORE this process has imported torch or touched the GPU — the ranks are fresh children."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -366,6 +744,16 @@ def main():
                     help="detector forwards per page (dit_trocr): 1 = bbox_refinement False (the headline); 3 = the worst "
                          "case of the reference's default refinement loop (psm_sparse re-runs the detector on the "
                          "blacked-out page up to 3 times)")
+    ap.add_argument("--serial", action="store_true",
+                    help="dit_trocr: detector and recognizer one after the other instead of on two streams (what "
+                         "roofline.isolated measures; for rocprofv3 runs of the isolated kernels)")
+    ap.add_argument("--stream-pages", type=int, default=-1,
+                    help="dit_trocr, BASELINE configs[3]: also time a fixed stream of this many pages sharded over the ranks "
+                         "with the results gathered in page order (default: 2048 when N > 1, off at N = 1; 0 = off)")
+    ap.add_argument("--mixed-pages", type=int, default=48,
+                    help="dit_trocr, BASELINE configs[4]: pages per GPU of the mixed-DPI stream leg (multiple of 24)")
+    ap.add_argument("--no-mixed-dpi", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip det_passes_3 and the engine_api legs (N = 1)")
     ap.add_argument("--crops", choices=["lines", "detector"], default="lines")
     ap.add_argument("--inflight", type=int, default=6,
                     help="page pipelines per GPU (one context + stream + host thread each): the host-side box "
@@ -382,14 +770,20 @@ def main():
         args.workload = "craft_crnn"
     if args.pages <= 0:
         args.pages = 32 if args.workload == "dit_trocr" else 12
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # N > 1 without a launcher: become the launcher (nothing below this line has run, no GPU call has been made)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for the wrong N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # Rehearsal of the N > 1 path on a ONE-GPU box (not for measurements): MARIE_BENCH_REHEARSE=1 puts every rank on
@@ -397,6 +791,8 @@ def main():
     rehearse = os.environ.get("MARIE_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -648,7 +1044,8 @@ def main():
                 "avg_launch_ms": k["total_ms"] / max(k["launches"], 1),
                 "algorithmic_gflop_per_step": flops_step / 1e9,
             }
-            out["kernels_ms_per_step"] = {name: v["total_ms"] / prof_steps for name, v in prof.items() if v["launches"]}
+            out["kernels_ms_per_step"] = {name: v["total_ms"] / prof_steps for name, v in prof.items()
+                                          if v["launches"] and name not in IGEMM_VARIANTS}
             out["kernel_ms_over_wall_ms"] = sum(out["kernels_ms_per_step"].values()) / (1e3 * dt / args.steps)
         if world == 1 and not args.no_cpu_baseline:
             if args.workload == "craft_crnn":

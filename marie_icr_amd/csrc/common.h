@@ -24,7 +24,14 @@ enum MhipKernelId {
   MHIP_K_VIT_OPS = 9,     // LayerNorm, patch extraction, token/map moves (HBM-bound)
   MHIP_K_DET_OPS = 10,    // detector heads: anchors/decode, top-k, NMS, ROIAlign
   MHIP_K_DEC_OPS = 11,    // text decoder steps: embedding, single-query attention over caches, beam candidates
-  MHIP_K_COUNT = 12
+  // conv_igemm by tile shape: their launches are ALSO counted in MHIP_K_CONV_IGEMM (ProfSlot::parent), so that the fraction of
+  // the MFMA peak can be recomputed per variant from a profile (names as the kernels appear in a rocprofv3 trace)
+  MHIP_K_IGEMM_T64 = 12,    // conv_igemm_kernel<.., 64, ..>   512 x 64 tile
+  MHIP_K_IGEMM_T128 = 13,   // conv_igemm_kernel<.., 128, ..>  256 x 128 tile
+  MHIP_K_IGEMM_T256 = 14,   // conv_igemm_kernel<.., 256, ..>  256 x 256 tile
+  MHIP_K_IGEMM_S128 = 15,   // conv_igemm_kernel<.., 1128, ..> 128 x 128 tile (few-row GEMMs)
+  MHIP_K_IGEMM_PATCH = 16,  // conv3x3_patch_kernel            3x3 / pad 1 convolutions
+  MHIP_K_COUNT = 17
 };
 
 constexpr int MHIP_ZERO_BYTES = 65536;
@@ -33,6 +40,7 @@ struct ProfSlot {
   double total_ms = 0.0;
   int64_t launches = 0;
   double flops = 0.0;     // algorithmic FLOPs of the launches timed so far (MFMA kernels only)
+  int parent = -1;        // slot that also accumulates this one's time / launches / flops
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 

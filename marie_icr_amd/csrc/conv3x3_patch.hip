@@ -302,15 +302,15 @@ int launch_patch(mhip_ctx* ctx, const IgemmArgs& a, int pool, int pw_shift, int 
   }
   switch (pool) {
     case POOL_NONE:
-      PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM, hipLaunchKernelGGL((conv3x3_patch_kernel<T, POOL_NONE, BN_>), grid, block, lds,
+      PROF_LAUNCH(ctx, MHIP_K_IGEMM_PATCH, hipLaunchKernelGGL((conv3x3_patch_kernel<T, POOL_NONE, BN_>), grid, block, lds,
                                                              ctx->stream, a, pw_shift, np_pad, npieces));
       break;
     case POOL_2x2:
-      PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM, hipLaunchKernelGGL((conv3x3_patch_kernel<T, POOL_2x2, BN_>), grid, block, lds,
+      PROF_LAUNCH(ctx, MHIP_K_IGEMM_PATCH, hipLaunchKernelGGL((conv3x3_patch_kernel<T, POOL_2x2, BN_>), grid, block, lds,
                                                              ctx->stream, a, pw_shift, np_pad, npieces));
       break;
     default:
-      PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM, hipLaunchKernelGGL((conv3x3_patch_kernel<T, POOL_2x1, BN_>), grid, block, lds,
+      PROF_LAUNCH(ctx, MHIP_K_IGEMM_PATCH, hipLaunchKernelGGL((conv3x3_patch_kernel<T, POOL_2x1, BN_>), grid, block, lds,
                                                              ctx->stream, a, pw_shift, np_pad, npieces));
       break;
   }

@@ -595,6 +595,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 
 template <typename T, int BN_>
 int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
+  constexpr int KID = BN_ == 64 ? MHIP_K_IGEMM_T64 : (BN_ == 128 ? MHIP_K_IGEMM_T128 : MHIP_K_IGEMM_T256);
   dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(NTHREADS);
   const size_t lds = Cfg<BN_>::LDS_BYTES;
   static bool attr_set = false;
@@ -608,20 +609,20 @@ int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
     attr_set = true;
   }
   if (a.in2) {
-    PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+    PROF_LAUNCH(ctx, KID,
                 hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, BN_, true>), grid, block, lds, ctx->stream, a));
   } else {
     switch (pool) {
       case POOL_NONE:
-        PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+        PROF_LAUNCH(ctx, KID,
                     hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, BN_, false>), grid, block, lds, ctx->stream, a));
         break;
       case POOL_2x2:
-        PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+        PROF_LAUNCH(ctx, KID,
                     hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x2, BN_, false>), grid, block, lds, ctx->stream, a));
         break;
       default:
-        PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+        PROF_LAUNCH(ctx, KID,
                     hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_2x1, BN_, false>), grid, block, lds, ctx->stream, a));
         break;
     }
@@ -641,7 +642,7 @@ int launch_small(mhip_ctx* ctx, const IgemmArgs& a) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, POOL_NONE, 1128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  PROF_LAUNCH(ctx, MHIP_K_CONV_IGEMM,
+  PROF_LAUNCH(ctx, MHIP_K_IGEMM_S128,
               hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, 1128, false>), grid, block, lds, ctx->stream, a));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "conv_igemm launch: %s", hipGetErrorString(e));
@@ -716,9 +717,11 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.relu = d.relu;
   a.out_f32 = d.out_f32;
   a.PH = a.PW = a.tiles_x = a.tiles_y = 0;
-  if (ctx->profiling) ctx->prof[MHIP_K_CONV_IGEMM].flops += mhip_conv_flops(d);
+  const double fl = ctx->profiling ? mhip_conv_flops(d) : 0.0;
+  if (ctx->profiling) ctx->prof[MHIP_K_CONV_IGEMM].flops += fl;
   {
     const int r = mhip_try_launch_conv3x3_patch(ctx, precision, d, a);   // 3x3 / pad 1 / dense: patch kernel
+    if (r == 0) ctx->prof[MHIP_K_IGEMM_PATCH].flops += fl;
     if (r <= 0) return r;
   }
   static const int force_bn = getenv("MARIE_HIP_FORCE_BN") ? atoi(getenv("MARIE_HIP_FORCE_BN")) : 0;   // tuning aid
@@ -730,8 +733,10 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   if (a.mtiles * a.ntiles < 192 && a.N > 64 && d.pool == POOL_NONE && !d.in2) {
     a.mtiles = (a.M + 127) / 128;
     a.ntiles = (a.N + 127) / 128;
+    ctx->prof[MHIP_K_IGEMM_S128].flops += fl;
     return precision == MHIP_PREC_F16 ? launch_small<_Float16>(ctx, a) : launch_small<float>(ctx, a);
   }
+  ctx->prof[bn == 64 ? MHIP_K_IGEMM_T64 : (bn == 128 ? MHIP_K_IGEMM_T128 : MHIP_K_IGEMM_T256)].flops += fl;
   if (precision == MHIP_PREC_F16)
     return bn == 256 ? launch_t<_Float16, 256>(ctx, a, d.pool)
                      : (bn == 128 ? launch_t<_Float16, 128>(ctx, a, d.pool) : launch_t<_Float16, 64>(ctx, a, d.pool));

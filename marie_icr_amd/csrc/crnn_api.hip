@@ -23,7 +23,9 @@ int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...) {
 
 static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "lstm_rec",   "ctc_decode",
                                                  "image_ops",  "ccl",        "crop_batch", "attn",
-                                                 "attn_flash", "vit_ops",    "det_ops",    "dec_ops"};
+                                                 "attn_flash", "vit_ops",    "det_ops",    "dec_ops",
+                                                 "conv_igemm<64>", "conv_igemm<128>", "conv_igemm<256>", "conv_igemm<1128>",
+                                                 "conv3x3_patch"};
 
 extern "C" int mhip_kernel_count(void) { return MHIP_K_COUNT; }
 extern "C" const char* mhip_kernel_name(int k) { return (k >= 0 && k < MHIP_K_COUNT) ? kKernelNames[k] : ""; }
@@ -37,6 +39,7 @@ extern "C" int mhip_init(int device_id, mhip_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return MHIP_EHIP;
   mhip_ctx* ctx = new mhip_ctx();
   ctx->device = device_id;
+  for (int k = MHIP_K_IGEMM_T64; k <= MHIP_K_IGEMM_PATCH; ++k) ctx->prof[k].parent = MHIP_K_CONV_IGEMM;
   if (hipMalloc(&ctx->zeros, MHIP_ZERO_BYTES) != hipSuccess || hipMemset(ctx->zeros, 0, MHIP_ZERO_BYTES) != hipSuccess) {
     delete ctx;
     return MHIP_ENOMEM;
@@ -138,6 +141,10 @@ static void prof_drain(mhip_ctx* ctx) {
       if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
         s.total_ms += ms;
         s.launches += 1;
+        if (s.parent >= 0) {
+          ctx->prof[s.parent].total_ms += ms;
+          ctx->prof[s.parent].launches += 1;
+        }
       }
       ctx->event_pool.push_back(p.first);
       ctx->event_pool.push_back(p.second);

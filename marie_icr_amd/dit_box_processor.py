@@ -87,14 +87,20 @@ class BoxProcessorUlimDit:
 
     def __init__(self, work_dir: str = "/tmp/boxes", models_dir: Optional[str] = None, cuda: bool = False,
                  refinement: bool = True, *, state: Optional[Dict[str, np.ndarray]] = None, model: str = "large",
-                 precision: str = "f16", device_id: int = 0, ctx: Optional[Context] = None, config=None, det_batch: int = 8):
+                 precision: str = "f16", device_id: int = 0, ctx: Optional[Context] = None, config=None, det_batch: int = 8,
+                 dit_model: Optional[DitModel] = None):
         if not cuda:
             raise MarieHipError("BoxProcessorUlimDit here is the MI355X path; cuda=False has no implementation")
         self.work_dir = work_dir
         self.cuda = cuda
         self.refinement = refinement
         self.strict_box_segmentation = False
-        self.ctx = ctx or Context(device_id)
+        self.ctx = ctx or (dit_model.ctx if dit_model is not None else Context(device_id))
+        if dit_model is not None:            # an already-loaded detector (its weights stay where they are)
+            self.model = dit_model
+            self.det_batch = int(det_batch)
+            self.min_size_test = [self.model.cfg.min_size_test, self.model.cfg.min_size_test]
+            return
         if state is None:
             if models_dir is None:
                 raise ValueError("either `state` or `models_dir` is required")

@@ -185,13 +185,14 @@ class TrOcrProcessor(OcrProcessor):
     def __init__(self, work_dir: str = "/tmp/icr", model_name_or_path: Optional[str] = None, cuda: bool = True, *,
                  state: Optional[Dict[str, np.ndarray]] = None, config: Optional[TrocrConfig] = None, model: str = "base",
                  precision: str = "f16", device_id: int = 0, ctx: Optional[Context] = None, dict_path: Optional[str] = None,
-                 encoder_json: Optional[str] = None, batch_size: int = 256, **kwargs) -> None:
+                 encoder_json: Optional[str] = None, batch_size: int = 256, trocr_model: Optional[TrocrModel] = None,
+                 **kwargs) -> None:
         super().__init__(work_dir, cuda)
         if not cuda:
             raise MarieHipError("TrOcrProcessor here is the MI355X path; cuda=False has no implementation")
-        self.ctx = ctx or Context(device_id)
-        cfg = config or default_config(self.ctx.lib, model)
-        if state is None:
+        self.ctx = ctx or (trocr_model.ctx if trocr_model is not None else Context(device_id))
+        cfg = trocr_model.cfg if trocr_model is not None else (config or default_config(self.ctx.lib, model))
+        if state is None and trocr_model is None:
             if model_name_or_path is None or not os.path.exists(model_name_or_path):
                 raise FileNotFoundError(f"File not found : {model_name_or_path}")
             import torch
@@ -207,7 +208,7 @@ class TrOcrProcessor(OcrProcessor):
             raise ValueError(f"dictionary has {len(self.symbols)} symbols, the model expects {cfg.vocab}")
         self.bpe = Gpt2Decoder(encoder_json) if encoder_json else None
         prec = {"f16": PREC_F16, "fp16": PREC_F16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
-        self.model = TrocrModel(self.ctx, state, cfg, prec)
+        self.model = trocr_model if trocr_model is not None else TrocrModel(self.ctx, state, cfg, prec)
         self.batch_size = int(batch_size)
 
     def is_available(self) -> bool:

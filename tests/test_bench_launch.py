@@ -1,0 +1,67 @@
+"""bench.py's N > 1 entry: `python bench.py --gpus N` starts the ranks itself, a WORLD_SIZE that disagrees with --gpus is
+refused, and (GPU box) the two-rank rehearsal on one GPU runs the sharded stream / work-queue legs and gathers the same
+results as one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    r = _run(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_gpus_flag_without_launcher_starts_ranks_and_propagates_failure():
+    """No GPU here: the two child ranks start (torch.distributed.run banner) and fail loudly; bench.py must exit non-zero
+    instead of silently measuring one device."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    r = _run(["--gpus", "2", "--steps", "1"], timeout=300)
+    assert r.returncode != 0
+    assert "needs an MI355X" in (r.stderr + r.stdout)
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_matches_one_rank():
+    """MARIE_BENCH_REHEARSE=1 python bench.py --gpus 2 on one GPU (gloo for the start-up broadcast / gathers, both ranks on
+    device 0): n_gpus is 2, the weight broadcast checksum passed, and the stream / mixed-DPI results gathered from two ranks
+    equal the one-rank results (order-sensitive checksums)."""
+    common = ["--steps", "1", "--warmup", "1", "--pages", "4", "--det-batch", "4", "--decode-len", "3", "--stream-pages", "12",
+              "--mixed-pages", "24", "--no-cpu-baseline", "--no-kernel-timing", "--no-secondary", "--host-steps", "0"]
+    one = _json_line(_run(["--gpus", "1"] + common).stdout)
+    r = _run(["--gpus", "2"] + common, {"MARIE_BENCH_REHEARSE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    two = _json_line(r.stdout)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["stream"]["pages"] == one["stream"]["pages"] == 12
+    assert two["stream"]["pages_per_rank"] == 6 and two["stream"]["scaling"] == "strong"
+    assert two["stream"]["result_checksum"] == one["stream"]["result_checksum"]
+    # the mixed-DPI leg processes 24 pages per rank: compare the first 24 pages' structure through the checksum of a 1-rank
+    # run over the same 48 pages
+    one48 = _json_line(_run(["--gpus", "1"] + [a if a != "24" else "48" for a in common]).stdout)
+    assert two["mixed_dpi"]["pages"] == one48["mixed_dpi"]["pages"] == 48
+    assert two["mixed_dpi"]["result_checksum"] == one48["mixed_dpi"]["result_checksum"]

@@ -233,11 +233,11 @@ def test_box_processor_vs_oracle_pipeline(ctx, small_case):
         np.testing.assert_array_equal(np.asarray(l1), np.asarray(l2))
 
     # (1) oracle detector under the product control flow
-    gpu_detect = bp._detect
-    bp._detect = lambda page_dev, shape: o.det.detect(page_dev.cpu().numpy())
+    gpu_detect = bp._detect_batch
+    bp._detect_batch = lambda page_devs, shape: [o.det.detect(d.cpu().numpy()) for d in page_devs]
     rects, frags, numbers, pred, lines = bp.extract_bounding_boxes("t", "k", page, PSMode.SPARSE)
     same((rects, frags, numbers, lines), (orects, ofrags, onumbers, olines))
-    bp._detect = gpu_detect
+    bp._detect_batch = gpu_detect
     # (2) GPU detector under the oracle's control flow == the product end to end
     rects, frags, numbers, pred, lines = bp.extract_bounding_boxes("t", "k", page, PSMode.SPARSE)
 
