@@ -351,6 +351,12 @@ int mhip_trocr_generate_host(mhip_trocr* m, const uint8_t* crops_host, int n, in
 /* fragments of any size (3 channels) inside one device buffer -> Pillow bicubic to img x img -> generate                    */
 int mhip_trocr_generate_fragments(mhip_trocr* m, const uint8_t* base_dev, const mhip_crop_desc* descs_host, int n,
                                   int swap_rb, int32_t* tokens_out, int32_t* lengths_out, float* scores_out);
+/* The decoder's encoder-attention stage alone (one layer, one step) on host inputs, through the f16 kernels that attend over
+ * the encoder tokens themselves (key / value projections absorbed: cross_attn.hip).  replaces: fairseq MultiheadAttention
+ * (encoder_attn) as TextRecognitionGenerator drives it, marie/models/unilm/trocr/generator.py:127-362.  q [crops*beam][heads*64]
+ * (projected, scaled), enc [crops][n_tok][enc_dim], wk / wv [heads*64][enc_dim], bv [heads*64] -> out [crops*beam][heads*64]. */
+int mhip_cross_attention_host(mhip_ctx* ctx, const float* q, const float* enc, const float* wk, const float* wv,
+                              const float* bv, int crops, int beam, int heads, int n_tok, int enc_dim, float* out);
 
 /* ---- word-box / line geometry of the DiT box processor (host, pure functions; no ctx) --------------------------------- */
 /* replaces: merge_boxes, marie/utils/overlap.py:268-330 (find_overlap_horizontal(center_y_overlap=0.5) :106-183,

@@ -31,7 +31,8 @@ enum MhipKernelId {
   MHIP_K_IGEMM_T256 = 14,   // conv_igemm_kernel<.., 256, ..>  256 x 256 tile
   MHIP_K_IGEMM_S128 = 15,   // conv_igemm_kernel<.., 1128, ..> 128 x 128 tile (few-row GEMMs)
   MHIP_K_IGEMM_PATCH = 16,  // conv3x3_patch_kernel            3x3 / pad 1 convolutions
-  MHIP_K_COUNT = 17
+  MHIP_K_CROSS_ATTN = 17,   // decoder encoder-attention over the encoder tokens themselves (absorbed K / V projections)
+  MHIP_K_COUNT = 18
 };
 
 constexpr int MHIP_ZERO_BYTES = 65536;
@@ -274,6 +275,24 @@ struct DecAttnDesc {
   int heads = 0, groups = 0, nq = 1, n_keys = 0;
 };
 int mhip_launch_decode_attention(mhip_ctx* ctx, int precision, const DecAttnDesc& d);
+// Encoder-attention of one decoder layer with the key / value projections absorbed (cross_attn.hip; f16 only):
+// q [crops*beam][ldq] (pre-scaled) -> qt = W_k,h^T q_h -> attention over E -> ct -> ao = W_v,h ct_h + b_v.
+struct CrossAbsorbDesc {
+  const void* q = nullptr;     // [crops*beam][ldq] f16
+  int ldq = 0;
+  const void* E = nullptr;     // [crops][kv_rows][enc_dim] f16 encoder tokens
+  int kv_rows = 0, n_keys = 0, enc_dim = 0;
+  const void* wkt = nullptr;   // [heads][enc_dim][64] f16: W_k[h*64 + j][d] * log2(e) at [h][d][j]
+  const void* wv = nullptr;    // [heads*64][enc_dim] f16 (the checkpoint's layout)
+  const float* bv = nullptr;   // [heads*64]
+  void* qt = nullptr;          // scratch [crops*beam][16][enc_dim] f16
+  void* ct = nullptr;          // scratch [crops*beam][16][enc_dim] f16
+  void* ao = nullptr;          // [crops*beam][ldo] f16
+  int ldo = 0;
+  int crops = 0, beam = 1, heads = 0;
+};
+bool mhip_cross_absorb_supported(int enc_dim, int beam, int heads);
+int mhip_launch_cross_absorbed(mhip_ctx* ctx, const CrossAbsorbDesc& d);
 struct BeamCandDesc {
   const void* logits = nullptr;    // [bsz*beam][ld], fp32 or f16
   int logits_f16 = 0;

@@ -25,7 +25,7 @@ static const char* kKernelNames[MHIP_K_COUNT] = {"conv_first", "conv_igemm", "ls
                                                  "image_ops",  "ccl",        "crop_batch", "attn",
                                                  "attn_flash", "vit_ops",    "det_ops",    "dec_ops",
                                                  "conv_igemm<64>", "conv_igemm<128>", "conv_igemm<256>", "conv_igemm<1128>",
-                                                 "conv3x3_patch"};
+                                                 "conv3x3_patch", "cross_attn"};
 
 extern "C" int mhip_kernel_count(void) { return MHIP_K_COUNT; }
 extern "C" const char* mhip_kernel_name(int k) { return (k >= 0 && k < MHIP_K_COUNT) ? kKernelNames[k] : ""; }

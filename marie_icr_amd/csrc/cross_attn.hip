@@ -1,0 +1,345 @@
+// cross_attn.hip — the TrOCR decoder's encoder-attention with the key / value projections absorbed (f16 mode).
+//
+// What it replaces: fairseq MultiheadAttention(encoder_attn) of every decoder layer as TextRecognitionGenerator drives it
+// (marie/models/unilm/trocr/generator.py:127-362 -> TransformerDecoderLayer.encoder_attn), i.e. per layer, crop and step
+//     K = E W_k^T + b_k,  V = E W_v^T + b_v          (E: the crop's 577 encoder tokens of width ED, the SAME for all layers)
+//     o_h = softmax_s(q_h . K_h[s]) V_h                (q pre-scaled by head_dim^-0.5, one query per beam and head)
+// The straightforward kernel (trocr_ops.hip decode_attn) is HBM-bound on K and V: 2 x 577 x 1024 f16 = 2.36 MB per crop, layer
+// and step, after two projection GEMMs per layer.  Algebraically
+//     q_h . K_h[s]  =  (W_k,h^T q_h) . E[s] + q_h . b_k,h           the second term is constant over s: softmax drops it
+//     o_h           =  W_v,h (sum_s p[s] E[s]) + b_v,h              (sum_s p[s] = 1)
+// so attention can run over E itself with "absorbed" queries qt_h = W_k,h^T q_h (ED numbers per beam and head) and produce
+// contexts ct_h = sum_s p[s] E[s] that W_v,h maps back: 0.89 MB per crop, layer and step instead of 2.36, no K / V tensors
+// and no projection GEMMs.  Three kernels:
+//   absorb_q    qt[r][h][:]  = W_k,h^T q[r][h*64 : h*64+64]                                 (grouped GEMM, K = 64)
+//   cross_attn  one workgroup per crop, one wave per beam: S^T = E Qt^T and Ct^T = E^T P^T on the matrix cores
+//   absorb_v    ao[r][h*64 : h*64+64] = W_v,h ct[r][h][:] + b_v,h                           (grouped GEMM, K = ED)
+//
+// cross_attn, MI355X shape: E tiles of 32 keys x ED (48 KiB at ED = 768) go HBM -> LDS by LDS-DMA into a 3-slot ring (two
+// tiles in flight under the one being used); the tile is read twice from LDS — by rows (ds_read_b128: A operand of
+// S^T = E Qt^T, contraction over ED) and by columns (ds_read_b64_tr_b16: A operand of Ct^T = E^T P^T, contraction over keys) —
+// from ONE image: 16-byte chunks are XOR-swizzled inside every 256-byte group with x(row) = ((row & 7) << 1) | ((row >> 3) & 1),
+// applied on the DMA source side, which keeps both kinds of read (nearly) conflict-free.  S^T is computed transposed so that a
+// query is a lane column: the online soft-max is a per-lane loop plus two cross-lane max steps, keeps a stale reference (rescale
+// only when a tile exceeds it by 2^8) and the probabilities a lane holds are, converted to f16, directly the B operand of the
+// second product.  The wave's 16 queries are the 16 heads of its beam; Qt fragments (ED/32 x 4 VGPRs) live in registers, the
+// ED x 16 fp32 context accumulators (ED/4 registers) in AGPRs.  Bound: HBM (0.89 MB per crop against 85 MFLOP).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ half4v lds_tr16(const char* p) {
+  fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p);
+  return __builtin_bit_cast(half4v, v);
+}
+__device__ __forceinline__ int swz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct CrossArgs {
+  const _Float16* E;     // [crops][kv_rows][ED] encoder tokens (rows >= n_keys of a crop are finite padding)
+  const _Float16* qt;    // [crops*W][16][ED] absorbed queries (heads >= `heads` are not read)
+  _Float16* ct;          // [crops*W][16][ED] contexts
+  int kv_rows, n_keys, heads;
+};
+
+constexpr int TK = 32;   // keys per tile
+// ring slots that fit beside the score-exchange buffer (2 W waves x 2 KiB) in 160 KiB of LDS
+constexpr int cross_slots(int ed, int w) { return (3 * TK * ed * 2 + 4 * w * 1024 <= 160 * 1024) ? 3 : 2; }
+
+// 2 W waves: wave = (beam, half) — each wave owns one half of the ED dims for both products (so its Qt fragments and context
+// accumulators are ED/64 + ED/8 registers and everything stays in architectural VGPRs: the file is compiled with
+// -amdgpu-mfma-vgpr-form, a rescale of AGPR accumulators would cost two v_accvgpr moves per value).  The two partial score
+// tiles of a beam are exchanged through 2 KiB of LDS per wave.
+template <int ED, int W>
+__global__ __launch_bounds__(128 * W) void cross_attn_kernel(CrossArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = 2 * W;
+  constexpr int ROWB = ED * 2;                 // bytes of one key row
+  constexpr int HB = ED;                       // bytes of a wave's half row
+  constexpr int TILE_B = TK * ROWB;
+  constexpr int NS = cross_slots(ED, W);       // ring slots
+  constexpr int NI = TILE_B / 1024;            // LDS-DMA wave-instructions per tile
+  constexpr int NPW = (NI + NW - 1) / NW;      // per wave (the last ones of a tile may be missing for some waves)
+  constexpr int KS = ED / 64, MT = ED / 32;    // k-steps / 16-dim tiles of a half
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int beam = wave >> 1, hh = wave & 1;
+  const int n = lane & 15, g = lane >> 4;
+  const int crop = blockIdx.x;
+  const char* Ec = (const char*)p.E + (size_t)crop * p.kv_rows * ROWB;
+  const int ntiles = (p.n_keys + TK - 1) / TK;
+  float4v* xbuf = (float4v*)(smem + NS * TILE_B);          // [NW][2][64] partial score tiles
+
+  // ---- DMA plan: instruction i of a tile fills LDS bytes [1024 i, 1024 i + 1024); lane l's 16 bytes are row r, swizzled chunk cp
+  int dma_off[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int i = wave + j * NW;
+    const int byte = i * 1024 + lane * 16;
+    const int r = byte / ROWB, cp = (byte - r * ROWB) >> 4;
+    const int c = (cp & ~15) | ((cp & 15) ^ swz(r));
+    dma_off[j] = r * ROWB + c * 16;
+  }
+  auto issue = [&](int t, int slot) {
+    const char* src = Ec + (size_t)t * TILE_B;
+    char* dst = smem + slot * TILE_B;
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const int i = wave + j * NW;
+      if (NI % NW == 0 || i < NI) glds16(src + dma_off[j], dst + i * 1024);
+    }
+  };
+  // waves whose last instruction of a tile does not exist issue NPW - 1 per tile
+  const bool short_wave = (NI % NW != 0) && (wave + (NPW - 1) * NW >= NI);
+
+  // ---- absorbed queries of this beam, this half of the dims: B operand fragments, B[k = dim][n = head]
+  half8v qf[KS];
+  {
+    const _Float16* qr = p.qt + ((size_t)(crop * W + beam) * 16 + n) * ED + hh * (ED / 2) + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (n < p.heads) qf[ks] = *(const half8v*)(qr + ks * 32);
+      else qf[ks] = (half8v){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  // ---- LDS read offsets (bytes inside a tile)
+  // row reads: key row 16 mt + n, chunk 4 (ks & 3) + g of 256-byte group ks >> 2 of the wave's half row.  swz(16 + n) = swz(n):
+  // the second row tile is the first plus 16 rows (an immediate offset)
+  int a_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a_off[j] = n * ROWB + hh * HB + 16 * ((4 * j + g) ^ swz(n));
+  // transposed reads: key rows 4 g + q (+ 16), chunk 2 (mt & 7) + (pp >> 1) of group mt >> 3, half pp & 1.  With x = swz(row):
+  // 16 ((2 j + b) ^ x) = 32 (j ^ (x >> 1)) + 16 (b ^ (x & 1)), and x is the same for both row sets
+  int t_off[8];
+  {
+    const int q = n >> 2, pp = n & 3, row = 4 * g + q, x = swz(row);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t_off[j] = row * ROWB + hh * HB + 32 * (j ^ (x >> 1)) + 16 * ((pp >> 1) ^ (x & 1)) + 8 * (pp & 1);
+  }
+
+  float4v acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = (float4v){0.f, 0.f, 0.f, 0.f};
+  float mref = 0.f, lsum = 0.f;
+
+  issue(0, 0);
+  if (NS == 3 && ntiles > 1) issue(1, 1);
+  int slot = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t has landed once at most the DMA instructions of the tiles issued after it are outstanding
+    if (NS == 3 && t + 1 < ntiles) {
+      if (short_wave) wait_vm<(NPW > 1 ? NPW - 1 : 0)>();
+      else wait_vm<NPW>();
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (NS == 3) {
+      if (t + 2 < ntiles) issue(t + 2, slot == 0 ? 2 : slot - 1);   // the slot tile t - 1 occupied
+    } else if (t + 1 < ntiles) {
+      issue(t + 1, slot ^ 1);
+    }
+    const char* sb = smem + slot * TILE_B;
+    // ---- partial S^T[32 keys][16 heads] = E_tile[:, half] Qt[:, half]^T
+    float4v s[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8v a0 = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2));
+      const half8v a1 = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2) + 16 * ROWB);
+      s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, qf[ks], s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, qf[ks], s[1], 0, 0, 0);
+    }
+    // the other half's partial sums (same lane layout)
+    xbuf[(wave * 2 + 0) * 64 + lane] = s[0];
+    xbuf[(wave * 2 + 1) * 64 + lane] = s[1];
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the LDS writes above
+    __builtin_amdgcn_s_barrier();
+    s[0] += xbuf[((wave ^ 1) * 2 + 0) * 64 + lane];
+    s[1] += xbuf[((wave ^ 1) * 2 + 1) * 64 + lane];
+    // lane (n, g) holds head n, keys t*32 + 16 mt + 4 g + e.  Keys past the end: -inf.
+    const int key0 = t * TK;
+    if (key0 + TK > p.n_keys) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (key0 + 16 * mt + 4 * g + e >= p.n_keys) s[mt][e] = -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (t == 0) {
+      mref = mx;                                    // tile 0 always holds valid keys
+    } else if (__builtin_amdgcn_ballot_w64(mx > mref + 8.f) != 0) {   // stale reference: rescale only when a tile outgrows it
+      const float nr = fmaxf(mref, mx), f = __builtin_amdgcn_exp2f(mref - nr);
+      mref = nr;
+      lsum *= f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i] *= f;
+    }
+    half8v pf;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(s[mt][e] - mref);
+        lsum += pe;
+        pf[mt * 4 + e] = (_Float16)pe;
+      }
+    // ---- Ct^T[half of ED][16 heads] += E_tile[:, half]^T P^T
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const half4v lo = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3));
+      const half4v hi = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3) + 16 * ROWB);
+      const half8v a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf, acc[mt], 0, 0, 0);
+    }
+    slot = (slot == NS - 1) ? 0 : slot + 1;
+  }
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+  const float inv = 1.f / lsum;
+  if (n < p.heads) {
+    _Float16* o = p.ct + ((size_t)(crop * W + beam) * 16 + n) * ED + hh * (ED / 2) + 4 * g;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      half4v h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (_Float16)(acc[mt][e] * inv);
+      *(half4v*)(o + 16 * mt) = h;
+    }
+  }
+}
+
+// qt[r][h][d] = sum_j q[r][h*64 + j] wkt[h][d][j].  Computed transposed (rows of the output tile = dims, columns = 16 query
+// rows) so that a lane ends up with 4 consecutive dims of one (row, head): 8-byte stores.  grid (rows / 16, heads), 4 waves,
+// wave w = dims [w ED / 4, (w + 1) ED / 4).  log2(e) (the soft-max runs on exp2) is folded into wkt.
+template <int ED>
+__global__ __launch_bounds__(256) void absorb_q_kernel(const _Float16* __restrict__ q, int ldq, const _Float16* __restrict__ wkt,
+                                                      _Float16* __restrict__ qt, int rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, r = blockIdx.x * 16 + n;
+  half8v b[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    if (r < rows) b[ks] = *(const half8v*)(q + (size_t)r * ldq + h * 64 + ks * 32 + g * 8);
+    else b[ks] = (half8v){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  constexpr int MTW = ED / 64;      // 16-dim tiles per wave
+  const _Float16* wrow = wkt + ((size_t)h * ED + wave * (ED / 4) + n) * 64 + g * 8;
+  _Float16* out = qt + ((size_t)r * 16 + h) * ED + wave * (ED / 4) + 4 * g;
+#pragma unroll 4
+  for (int mt = 0; mt < MTW; ++mt) {
+    const half8v a0 = *(const half8v*)(wrow + (size_t)mt * 16 * 64);
+    const half8v a1 = *(const half8v*)(wrow + (size_t)mt * 16 * 64 + 32);
+    float4v c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[1], c, 0, 0, 0);
+    if (r < rows) {
+      half4v o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (_Float16)c[e];
+      *(half4v*)(out + mt * 16) = o;
+    }
+  }
+}
+
+// ao[r][h*64 + j] = sum_d ct[r][h][d] wv[h*64 + j][d] + bv[h*64 + j].  Transposed like absorb_q: output tile rows = j, columns =
+// 16 rows r.  grid (rows / 64, heads), 4 waves, wave w = rows [16 w, 16 w + 16) of the block.
+template <int ED>
+__global__ __launch_bounds__(256) void absorb_v_kernel(const _Float16* __restrict__ ct, const _Float16* __restrict__ wv,
+                                                      const float* __restrict__ bv, _Float16* __restrict__ ao, int ldo, int rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, r = blockIdx.x * 64 + wave * 16 + n;
+  const _Float16* brow = ct + ((size_t)min(r, rows - 1) * 16 + h) * ED + g * 8;
+  const _Float16* arow = wv + ((size_t)h * 64 + n) * ED + g * 8;
+  float4v c[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) c[mt] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int ks = 0; ks < ED / 32; ++ks) {
+    const half8v b = *(const half8v*)(brow + ks * 32);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const half8v a = *(const half8v*)(arow + (size_t)mt * 16 * ED + ks * 32);
+      c[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c[mt], 0, 0, 0);
+    }
+  }
+  if (r >= rows) return;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const float4v bb = *(const float4v*)(bv + h * 64 + mt * 16 + 4 * g);
+    half4v o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (_Float16)(c[mt][e] + bb[e]);
+    *(half4v*)(ao + (size_t)r * ldo + h * 64 + mt * 16 + 4 * g) = o;
+  }
+}
+
+template <int ED>
+int launch_ed(mhip_ctx* ctx, const CrossAbsorbDesc& d) {
+  const int rows = d.crops * d.beam;
+  PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL((absorb_q_kernel<ED>), dim3((rows + 15) / 16, d.heads), dim3(256), 0, ctx->stream,
+                                                     (const _Float16*)d.q, d.ldq, (const _Float16*)d.wkt, (_Float16*)d.qt, rows));
+  CrossArgs a;
+  a.E = (const _Float16*)d.E; a.qt = (const _Float16*)d.qt; a.ct = (_Float16*)d.ct;
+  a.kv_rows = d.kv_rows; a.n_keys = d.n_keys; a.heads = d.heads;
+  constexpr int TILE_B = TK * ED * 2;
+  const size_t lds = (size_t)cross_slots(ED, d.beam) * TILE_B + (size_t)d.beam * 4096;
+#define CROSS_LAUNCH(WV)                                                                                                       \
+  do {                                                                                                                         \
+    static bool attr = false;                                                                                                  \
+    if (!attr) {                                                                                                               \
+      (void)hipFuncSetAttribute((const void*)cross_attn_kernel<ED, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr = true;                                                                                                             \
+    }                                                                                                                          \
+    PROF_LAUNCH(ctx, MHIP_K_CROSS_ATTN,                                                                                        \
+                hipLaunchKernelGGL((cross_attn_kernel<ED, WV>), dim3(d.crops), dim3(128 * WV), lds, ctx->stream, a));          \
+  } while (0)
+  switch (d.beam) {
+    case 1: CROSS_LAUNCH(1); break;
+    case 2: CROSS_LAUNCH(2); break;
+    case 3: CROSS_LAUNCH(3); break;
+    default: CROSS_LAUNCH(4); break;
+  }
+#undef CROSS_LAUNCH
+  PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL((absorb_v_kernel<ED>), dim3((rows + 63) / 64, d.heads), dim3(256), 0, ctx->stream,
+                                                     (const _Float16*)d.ct, (const _Float16*)d.wv, d.bv, (_Float16*)d.ao, d.ldo, rows));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "cross_attn launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace
+
+bool mhip_cross_absorb_supported(int enc_dim, int beam, int heads) {
+  return (enc_dim == 256 || enc_dim == 512 || enc_dim == 768 || enc_dim == 1024) && beam >= 1 && beam <= 4 && heads >= 1 && heads <= 16;
+}
+
+int mhip_launch_cross_absorbed(mhip_ctx* ctx, const CrossAbsorbDesc& d) {
+  if (!d.q || !d.E || !d.wkt || !d.wv || !d.bv || !d.qt || !d.ct || !d.ao || d.crops < 1)
+    return mhip_fail(ctx, MHIP_EINVAL, "cross_attn: null operand");
+  if (!mhip_cross_absorb_supported(d.enc_dim, d.beam, d.heads) || d.n_keys < 1 || d.kv_rows < d.n_keys || d.ldq % 8 || d.ldo % 4)
+    return mhip_fail(ctx, MHIP_EINVAL, "cross_attn: unsupported shape (enc_dim %d, beam %d, heads %d)", d.enc_dim, d.beam, d.heads);
+  switch (d.enc_dim) {
+    case 256: return launch_ed<256>(ctx, d);
+    case 512: return launch_ed<512>(ctx, d);
+    case 768: return launch_ed<768>(ctx, d);
+    default: return launch_ed<1024>(ctx, d);
+  }
+}

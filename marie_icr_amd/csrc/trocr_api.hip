@@ -29,6 +29,7 @@ struct mhip_trocr {
   size_t frag_crops_bytes = 0;
   void* frag_scratch = nullptr;
   size_t frag_scratch_bytes = 0;
+  bool absorb = false;       // encoder-attention with absorbed K / V projections (f16 mode)
   size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
 };
 
@@ -73,6 +74,9 @@ extern "C" int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_
   if (rc) return rc;
   mhip_trocr* m = new mhip_trocr();
   m->ctx = ctx; m->precision = precision; m->cfg = c; m->vit = vit;
+  // f16 mode: encoder-attention over the encoder tokens themselves (cross_attn.hip); MARIE_HIP_NO_ABSORB=1 keeps the projected
+  // K / V path (A/B measurements)
+  m->absorb = precision == MHIP_PREC_F16 && mhip_cross_absorb_supported(c.enc_dim, c.beam, c.dec_heads) && !getenv("MARIE_HIP_NO_ABSORB");
   const size_t es = m->esz(), D = c.dec_dim, E = c.enc_dim, F = c.dec_ffn;
   Arena& a = m->arena;
   a.take("emb", (size_t)c.vocab * D * es);
@@ -82,6 +86,7 @@ extern "C" int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_
   for (int l = 0; l < c.dec_layers; ++l) {
     for (const char* n : {"sa_q", "sa_k", "sa_v", "sa_o", "ca_q", "ca_o"}) { a.take(lay(l, n) + "_w", D * D * es); a.take(lay(l, n) + "_b", D * 4); }
     for (const char* n : {"ca_k", "ca_v"}) { a.take(lay(l, n) + "_w", D * E * es); a.take(lay(l, n) + "_b", D * 4); }
+    if (m->absorb) a.take(lay(l, "ca_kt"), D * E * 2);     // W_k per head, transposed, x log2(e): [heads][E][64] f16
     a.take(lay(l, "fc1_w"), F * D * es); a.take(lay(l, "fc1_b"), F * 4);
     a.take(lay(l, "fc2_w"), D * F * es); a.take(lay(l, "fc2_b"), D * 4);
     for (const char* n : {"sa_ln", "ca_ln", "fin_ln"}) { a.take(lay(l, n) + "_g", D * 4); a.take(lay(l, n) + "_b", D * 4); }
@@ -182,6 +187,15 @@ extern "C" int mhip_trocr_finalize(mhip_trocr* m) {
         memcpy(a.h(lay(l, L.name) + "_b"), b->data.data(), (size_t)L.out * 4);
       }
     }
+    if (m->absorb) {
+      const HostTensor* wk = st.find(ctx, p + "encoder_attn.k_proj.weight", {D, E});
+      if (!wk) return MHIP_ESTATE;
+      _Float16* kt = (_Float16*)a.h(lay(l, "ca_kt"));
+      const float log2e = 1.4426950408889634f;
+      for (int h = 0; h < c.dec_heads; ++h)
+        for (int d = 0; d < E; ++d)
+          for (int j = 0; j < 64; ++j) kt[((size_t)h * E + d) * 64 + j] = (_Float16)(wk->data[(size_t)(h * 64 + j) * E + d] * log2e);
+    }
     const std::pair<const char*, std::string> lns[] = {{"sa_ln", p + "self_attn_layer_norm"}, {"ca_ln", p + "encoder_attn_layer_norm"},
                                                        {"fin_ln", p + "final_layer_norm"}};
     for (const auto& ln : lns) {
@@ -209,7 +223,8 @@ static size_t trocr_ws_bytes(const mhip_trocr* m, int n) {
   vit_geometry(m->vit, c.img_size, c.img_size, &vg);
   const size_t ldv = (c.vocab + 7) / 8 * 8;
   size_t b = vit_workspace_bytes(m->vit, n, vg);
-  b += 2 * (size_t)c.dec_layers * n * vg.npad * D * es;               // cross K / V
+  if (m->absorb) b += 2 * M * 16 * (size_t)c.enc_dim * 2 + 512;      // absorbed queries / contexts
+  else b += 2 * (size_t)c.dec_layers * n * vg.npad * D * es;          // cross K / V
   b += 2 * (size_t)c.dec_layers * (ML + 1) * M * D * es;              // self K / V history
   b += M * D * 4 + 3 * M * D * es + M * c.dec_ffn * es + M * ldv * 4; // x, xt, q, ao, hidden, logits
   b += 2 * M * (ML + 2) * 4 + 4 * M * 4 + (size_t)n * 2 * c.beam * 12 + (size_t)vg.n_tok * c.enc_dim * 4 + (size_t)c.vocab * 4 + 4096;
@@ -249,9 +264,11 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
   }
   // ---- encoder keys / values of every decoder layer (static over the steps) -----------------------------------------
   const size_t cross_l = (size_t)n * vg.npad * D * es;
-  char* ck = ws.take(L * cross_l);
-  char* cv = ws.take(L * cross_l);
-  for (int l = 0; l < L; ++l) {
+  char* ck = m->absorb ? nullptr : ws.take(L * cross_l);
+  char* cv = m->absorb ? nullptr : ws.take(L * cross_l);
+  char* qt = m->absorb ? ws.take((size_t)M * 16 * E * 2) : nullptr;
+  char* ct = m->absorb ? ws.take((size_t)M * 16 * E * 2) : nullptr;
+  for (int l = 0; l < L && !m->absorb; ++l) {
     if ((rc = mhip_gemm(ctx, prec, run.tokens, a.d(lay(l, "ca_k") + "_w"), (long long)n * vg.npad, D, E, nullptr, a.d<float>(lay(l, "ca_k") + "_b"), ck + l * cross_l, ACT_NONE, 0))) return rc;
     if ((rc = mhip_gemm(ctx, prec, run.tokens, a.d(lay(l, "ca_v") + "_w"), (long long)n * vg.npad, D, E, nullptr, a.d<float>(lay(l, "ca_v") + "_b"), cv + l * cross_l, ACT_NONE, 0))) return rc;
   }
@@ -318,10 +335,18 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
       if ((rc = mhip_launch_layernorm2(ctx, prec, x, a.d<float>(lay(l, "sa_ln") + "_g"), a.d<float>(lay(l, "sa_ln") + "_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
       // attention over the crop's encoder tokens (keys / values shared by its beams)
       if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "ca_q") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "ca_q") + "_b"), qb, ACT_NONE, 0))) return rc;
-      DecAttnDesc ca;
-      ca.q = qb; ca.k = ck + l * cross_l; ca.v = cv + l * cross_l; ca.out = ao; ca.kv_rows = vg.npad;
-      ca.ldq = ca.ldk = ca.ldo = D; ca.heads = c.dec_heads; ca.groups = n; ca.nq = beam; ca.n_keys = vg.n_tok;
-      if ((rc = mhip_launch_decode_attention(ctx, prec, ca))) return rc;
+      if (m->absorb) {
+        CrossAbsorbDesc cd;
+        cd.q = qb; cd.ldq = D; cd.E = run.tokens; cd.kv_rows = vg.npad; cd.n_keys = vg.n_tok; cd.enc_dim = E;
+        cd.wkt = a.d(lay(l, "ca_kt")); cd.wv = a.d(lay(l, "ca_v") + "_w"); cd.bv = a.d<float>(lay(l, "ca_v") + "_b");
+        cd.qt = qt; cd.ct = ct; cd.ao = ao; cd.ldo = D; cd.crops = n; cd.beam = beam; cd.heads = c.dec_heads;
+        if ((rc = mhip_launch_cross_absorbed(ctx, cd))) return rc;
+      } else {
+        DecAttnDesc ca;
+        ca.q = qb; ca.k = ck + l * cross_l; ca.v = cv + l * cross_l; ca.out = ao; ca.kv_rows = vg.npad;
+        ca.ldq = ca.ldk = ca.ldo = D; ca.heads = c.dec_heads; ca.groups = n; ca.nq = beam; ca.n_keys = vg.n_tok;
+        if ((rc = mhip_launch_decode_attention(ctx, prec, ca))) return rc;
+      }
       if ((rc = mhip_gemm(ctx, prec, ao, a.d(lay(l, "ca_o") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "ca_o") + "_b"), x, ACT_NONE, 1, x))) return rc;
       if ((rc = mhip_launch_layernorm2(ctx, prec, x, a.d<float>(lay(l, "ca_ln") + "_g"), a.d<float>(lay(l, "ca_ln") + "_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
       // feed-forward
@@ -474,4 +499,50 @@ extern "C" int mhip_trocr_generate_fragments(mhip_trocr* m, const uint8_t* base_
   int rc = mhip_pil_resize_fragments(ctx, base_dev, descs_host, n, m->frag_crops, S, S, MHIP_PIL_BICUBIC, m->frag_scratch, m->frag_scratch_bytes);
   if (!rc) rc = trocr_generate(m, m->frag_crops, n, swap_rb, tokens_out, lengths_out, scores_out, nullptr, nullptr);
   return rc;
+}
+
+
+// The decoder's encoder-attention stage on caller-supplied host inputs, through the absorbed kernels (f16 operands): what the
+// parity tests compare with fairseq's MultiheadAttention (q already projected and scaled).  q [crops*beam][heads*64],
+// enc [crops][n_tok][enc_dim], wk / wv [heads*64][enc_dim], bv [heads*64] -> out [crops*beam][heads*64], all fp32.
+extern "C" int mhip_cross_attention_host(mhip_ctx* ctx, const float* q, const float* enc, const float* wk, const float* wv,
+                                         const float* bv, int crops, int beam, int heads, int n_tok, int enc_dim, float* out) {
+  if (!ctx || !q || !enc || !wk || !wv || !bv || !out || crops < 1 || n_tok < 1) return MHIP_EINVAL;
+  if (!mhip_cross_absorb_supported(enc_dim, beam, heads)) return mhip_fail(ctx, MHIP_EINVAL, "cross_attention: unsupported shape");
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const int D = heads * 64, M = crops * beam, npad = (n_tok + 7) / 8 * 8;
+  const size_t rowsE = (size_t)crops * npad + 64;
+  std::vector<_Float16> hq((size_t)M * D), hE(rowsE * enc_dim, (_Float16)0.f), hkt((size_t)D * enc_dim), hwv((size_t)D * enc_dim);
+  for (size_t i = 0; i < hq.size(); ++i) hq[i] = (_Float16)q[i];
+  for (int c = 0; c < crops; ++c)
+    for (int s = 0; s < n_tok; ++s)
+      for (int d = 0; d < enc_dim; ++d) hE[((size_t)c * npad + s) * enc_dim + d] = (_Float16)enc[((size_t)c * n_tok + s) * enc_dim + d];
+  const float log2e = 1.4426950408889634f;
+  for (int h = 0; h < heads; ++h)
+    for (int d = 0; d < enc_dim; ++d)
+      for (int j = 0; j < 64; ++j) hkt[((size_t)h * enc_dim + d) * 64 + j] = (_Float16)(wk[(size_t)(h * 64 + j) * enc_dim + d] * log2e);
+  for (size_t i = 0; i < hwv.size(); ++i) hwv[i] = (_Float16)wv[i];
+  const size_t scr = (size_t)M * 16 * enc_dim * 2;
+  size_t need = hq.size() * 2 + hE.size() * 2 + hkt.size() * 2 + hwv.size() * 2 + (size_t)D * 4 + 2 * scr + (size_t)M * D * 2 + 4096;
+  int rc = mhip_ensure_workspace(ctx, need);
+  if (rc) return rc;
+  Carver ws(ctx->ws);
+  char* dq = ws.take(hq.size() * 2); char* dE = ws.take(hE.size() * 2); char* dkt = ws.take(hkt.size() * 2);
+  char* dwv = ws.take(hwv.size() * 2); float* dbv = ws.take<float>((size_t)D * 4);
+  char* qt = ws.take(scr); char* ct = ws.take(scr); char* ao = ws.take((size_t)M * D * 2);
+  MHIP_HIP(ctx, hipMemcpyAsync(dq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(dE, hE.data(), hE.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(dkt, hkt.data(), hkt.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(dwv, hwv.data(), hwv.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(dbv, bv, (size_t)D * 4, hipMemcpyHostToDevice, ctx->stream));
+  CrossAbsorbDesc cd;
+  cd.q = dq; cd.ldq = D; cd.E = dE; cd.kv_rows = npad; cd.n_keys = n_tok; cd.enc_dim = enc_dim;
+  cd.wkt = dkt; cd.wv = dwv; cd.bv = dbv; cd.qt = qt; cd.ct = ct; cd.ao = ao; cd.ldo = D;
+  cd.crops = crops; cd.beam = beam; cd.heads = heads;
+  if ((rc = mhip_launch_cross_absorbed(ctx, cd))) return rc;
+  std::vector<_Float16> ho((size_t)M * D);
+  MHIP_HIP(ctx, hipMemcpyAsync(ho.data(), ao, ho.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < ho.size(); ++i) out[i] = (float)ho[i];
+  return MHIP_OK;
 }

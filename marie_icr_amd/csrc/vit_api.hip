@@ -260,7 +260,7 @@ size_t vit_workspace_bytes(const mhip_vit* m, int B, const VitGeom& g) {
   add(R * D * es);             // attention output
   add(R * 4 * D * es);         // mlp hidden; also the patch matrix
   if (m->cfg.fpn) add(4 * (size_t)B * g.np * D * es);
-  else add(R * D * es);        // final tokens
+  else add((R + 64) * D * es); // final tokens (+ slack rows)
   return b;
 }
 
@@ -333,7 +333,10 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
   }
   run->tokens = nullptr;
   if (c.final_norm) {
-    run->tokens = ws.take(R * D * es);
+    // + 64 finite rows: the decoder's encoder-attention walks every image's tokens in 32-row tiles and so reads (masked) rows
+    // past the last image
+    run->tokens = ws.take((R + 64) * D * es);
+    MHIP_HIP(ctx, hipMemsetAsync(run->tokens + R * D * es, 0, (size_t)64 * D * es, ctx->stream));
     if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>("norm_g"), a.d<float>("norm_b"), run->tokens, (int)R, D, c.ln_eps))) return rc;
   }
   (void)tap_at;

@@ -145,3 +145,46 @@ def test_fp32_parity_with_unequal_encoder_and_decoder_widths(ctx, enc, dec, voca
         np.testing.assert_array_equal(gt, rt)
         assert abs(gs - rs) <= 1e-3
     m.close()
+
+
+@pytest.mark.parametrize("crops,beam,heads,n_tok,enc_dim", [
+    (5, 3, 16, 577, 768),      # trocr-base: 19 key tiles, the last one with 1 valid key
+    (3, 3, 4, 577, 256),       # the small test model
+    (2, 4, 8, 100, 512),       # beam 4, 8 heads, fewer keys than four tiles
+    (1, 1, 16, 33, 1024),      # trocr-large width (2-slot ring), a single hypothesis, one key in the second tile
+    (4, 2, 12, 64, 768),       # 12 heads: head slots 12..15 of a wave idle; exactly two full tiles
+])
+def test_encoder_attention_with_absorbed_projections(ctx, crops, beam, heads, n_tok, enc_dim):
+    """The f16 decoder attends over the encoder tokens themselves (W_k folded into the queries, W_v applied to the context;
+    cross_attn.hip).  Against fairseq's MultiheadAttention arithmetic in fp64 on the same f16-rounded operands: the absorbed
+    form drops q . b_k (constant over the keys) and must give the same output."""
+    import ctypes as C
+
+    rng = np.random.default_rng(crops * 1000 + enc_dim)
+    D, M = heads * 64, crops * beam
+    f16 = lambda a: a.astype(np.float16).astype(np.float32)
+    q = f16(rng.normal(0, 0.6, (M, D)))
+    enc = f16(rng.normal(0, 1.0, (crops, n_tok, enc_dim)))
+    wk = f16(rng.normal(0, 2.0 / np.sqrt(enc_dim), (D, enc_dim)))
+    wv = f16(rng.normal(0, 1.0 / np.sqrt(enc_dim), (D, enc_dim)))
+    bk = rng.normal(0, 0.5, (D,)).astype(np.float32)        # present in the reference computation only
+    bv = rng.normal(0, 0.3, (D,)).astype(np.float32)
+    enc[0, n_tok // 2] *= 6.0                                 # a dominant key well into the sequence: the stale reference must rescale
+    out = np.empty((M, D), np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = ctx.lib.mhip_cross_attention_host(ctx.h, vp(q), vp(np.ascontiguousarray(enc)), vp(wk), vp(wv), vp(bv), crops, beam, heads,
+                                           n_tok, enc_dim, vp(out))
+    assert rc == 0, ctx.last_error() if hasattr(ctx, "last_error") else rc
+    K = enc.astype(np.float64) @ wk.T.astype(np.float64) + bk            # (crops, n_tok, D)
+    V = enc.astype(np.float64) @ wv.T.astype(np.float64) + bv
+    ref = np.empty((M, D))
+    for r in range(M):
+        c = r // beam
+        for h in range(heads):
+            sl = slice(h * 64, h * 64 + 64)
+            s = K[c][:, sl] @ q[r, sl].astype(np.float64)
+            p = np.exp(s - s.max())
+            ref[r, sl] = (p / p.sum()) @ V[c][:, sl]
+    err = np.abs(out - ref).max()
+    assert err <= 2e-2 * max(1.0, np.abs(ref).max()), (err, np.abs(ref).max())
+    assert np.abs(out - ref).mean() <= 2e-3 * max(1.0, np.abs(ref).max())
