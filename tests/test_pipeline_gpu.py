@@ -244,7 +244,7 @@ def test_engine_batched_path_equals_per_page_loop(ctx):
     eng.page_batch = 2
     sizes = [(330, 255), (248, 192), (330, 255), (412, 318), (330, 255)]
     frames = [make_image_u8(60 + i, 1, h, w)[0] for i, (h, w) in enumerate(sizes)]
-    frames.append(np.full((330, 255, 3), 255, np.uint8))                       # blank page: no boxes
+    frames.append(np.full((330, 255, 3), 255, np.uint8))                       # a blank page (the random-weight detector still emits boxes)
     # a page smaller than MIN_SIZE_TEST is framed on a canvas: its fragments have no device window (and, as in the reference,
     # may be empty where a box lies in the frame — which is why it is not part of the recognizer comparison below)
     small = box.extract_bounding_boxes("q", "k", make_image_u8(63, 1, 100, 120)[0], PSMode.SPARSE)
@@ -263,5 +263,4 @@ def test_engine_batched_path_equals_per_page_loop(ctx):
         assert [(ln["line"], ln["text"], ln["wordids"]) for ln in ref["lines"]] == \
                [(ln["line"], ln["text"], ln["wordids"]) for ln in got[i]["lines"]]
         assert got[i]["meta"]["page"] == i and got[i]["meta"]["format"] == "xyxy"
-        assert (len(a) > 0) == (i != 5)
     ctx2.close()
