@@ -282,6 +282,7 @@ struct CrossAbsorbDesc {
   int ldq = 0;
   const void* E = nullptr;     // [crops][kv_rows][enc_dim] f16 encoder tokens
   int kv_rows = 0, n_keys = 0, enc_dim = 0;
+  int tiled = 0;               // 1: E is [key tile][crop][32 keys][enc_dim] (mhip_cross_tile_rows), kv_rows unused
   const void* wkt = nullptr;   // [heads][enc_dim][64] f16: W_k[h*64 + j][d] * log2(e) at [h][d][j]
   const void* wv = nullptr;    // [heads*64][enc_dim] f16 (the checkpoint's layout)
   const float* bv = nullptr;   // [heads*64]

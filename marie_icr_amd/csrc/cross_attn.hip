@@ -49,17 +49,112 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// wait until at most `tiles` x PER vector-memory operations are outstanding (tiles <= MAXT, wave-uniform)
+template <int PER, int MAXT>
+__device__ __forceinline__ void wait_vm_dyn(int tiles) {
+  if constexpr (MAXT <= 0 || PER <= 0) {
+    wait_vm<0>();
+  } else {
+    if (tiles >= MAXT) wait_vm<PER * MAXT>();
+    else wait_vm_dyn<PER, MAXT - 1>(tiles);
+  }
+}
 
 struct CrossArgs {
   const _Float16* E;     // [crops][kv_rows][ED] encoder tokens (rows >= n_keys of a crop are finite padding)
   const _Float16* qt;    // [crops*W][16][ED] absorbed queries (heads >= `heads` are not read)
   _Float16* ct;          // [crops*W][16][ED] contexts
-  int kv_rows, n_keys, heads;
+  size_t crop_stride, tile_stride;   // bytes from crop to crop / from a crop's key tile to its next one
+  int n_keys, heads;
 };
 
 constexpr int TK = 32;   // keys per tile
 // ring slots that fit beside the score-exchange buffer (2 W waves x 2 KiB) in 160 KiB of LDS
-constexpr int cross_slots(int ed, int w) { return (3 * TK * ed * 2 + 4 * w * 1024 <= 160 * 1024) ? 3 : 2; }
+constexpr int cross_slots(int ed, int w) {
+  const int n = (160 * 1024 - 4 * w * 1024) / (TK * ed * 2);
+  return n > 6 ? 6 : n;
+}
+
+// One key tile of one wave.  `sb` (the tile being read), `feed_dst` (the ring slot the DMA of a later tile fills) and `xb` (score
+// exchange) are distinct LDS regions; they are passed as __restrict__ pointers because that is what tells the compiler so: without
+// it every ds_read_b64_tr_b16 that follows a global_load_lds gets an s_waitcnt vmcnt(0) in front (the transposed-read intrinsic
+// carries no alias information), i.e. the whole ring drains before the second product — measured 306 us per launch against
+// 244 us for the DMA stream alone.
+template <int ED, int W, int NPW, int NI>
+__device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __restrict__ feed_dst, float4v* __restrict__ xb,
+                                           const char* __restrict__ feed_src, bool feed, const int (&dma_off)[NPW],
+                                           const int (&a_off)[4], const int (&t_off)[8], const half8v (&qf)[ED / 64],
+                                           float4v (&acc)[ED / 32], float& mref, float& lsum, int t, int n_keys, int wave, int lane) {
+  constexpr int NW = 2 * W, ROWB = ED * 2, KS = ED / 64, MT = ED / 32;
+  const int g = lane >> 4;
+    // ---- partial S^T[32 keys][16 heads] = E_tile[:, half] Qt[:, half]^T
+    float4v s[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
+    constexpr int EVERY = (KS / NPW) > 0 ? (KS / NPW) : 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // the DMA instructions of the tile that refills the slot freed at this tile's barrier go out now, as early as they may,
+      // one per k-step (not in one burst: the CU's vector-memory queue drains a 1 KiB instruction every ~33 cycles and a wave
+      // that issues 8 back to back waits in it with its LDS reads and MFMAs behind it)
+      if (ks % EVERY == 0 && ks / EVERY < NPW) {
+        const int j = ks / EVERY, i = wave + j * NW;
+        if (feed && (NI % NW == 0 || i < NI)) glds16(feed_src + dma_off[j], feed_dst + i * 1024);
+      }
+      const half8v a0 = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2));
+      const half8v a1 = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2) + 16 * ROWB);
+      s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, qf[ks], s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, qf[ks], s[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = (KS + EVERY - 1) / EVERY; j < NPW; ++j) {       // more DMA instructions than k-steps (narrow encoders)
+      const int i = wave + j * NW;
+      if (feed && (NI % NW == 0 || i < NI)) glds16(feed_src + dma_off[j], feed_dst + i * 1024);
+    }
+    // the other half's partial sums (same lane layout)
+    xb[(wave * 2 + 0) * 64 + lane] = s[0];
+    xb[(wave * 2 + 1) * 64 + lane] = s[1];
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the LDS writes above
+    __builtin_amdgcn_s_barrier();
+    s[0] += xb[((wave ^ 1) * 2 + 0) * 64 + lane];
+    s[1] += xb[((wave ^ 1) * 2 + 1) * 64 + lane];
+    // lane (n, g) holds head n, keys t*32 + 16 mt + 4 g + e.  Keys past the end: -inf.
+    const int key0 = t * TK;
+    if (key0 + TK > n_keys) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (key0 + 16 * mt + 4 * g + e >= n_keys) s[mt][e] = -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (t == 0) {
+      mref = mx;                                    // tile 0 always holds valid keys
+    } else if (__builtin_amdgcn_ballot_w64(mx > mref + 8.f) != 0) {   // stale reference: rescale only when a tile outgrows it
+      const float nr = fmaxf(mref, mx), f = __builtin_amdgcn_exp2f(mref - nr);
+      mref = nr;
+      lsum *= f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i] *= f;
+    }
+    half8v pf;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(s[mt][e] - mref);
+        lsum += pe;
+        pf[mt * 4 + e] = (_Float16)pe;
+      }
+    // ---- Ct^T[half of ED][16 heads] += E_tile[:, half]^T P^T
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const half4v lo = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3));
+      const half4v hi = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3) + 16 * ROWB);
+      const half8v a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf, acc[mt], 0, 0, 0);
+    }
+}
 
 // 2 W waves: wave = (beam, half) — each wave owns one half of the ED dims for both products (so its Qt fragments and context
 // accumulators are ED/64 + ED/8 registers and everything stays in architectural VGPRs: the file is compiled with
@@ -81,7 +176,7 @@ __global__ __launch_bounds__(128 * W) void cross_attn_kernel(CrossArgs p) {
   const int beam = wave >> 1, hh = wave & 1;
   const int n = lane & 15, g = lane >> 4;
   const int crop = blockIdx.x;
-  const char* Ec = (const char*)p.E + (size_t)crop * p.kv_rows * ROWB;
+  const char* Ec = (const char*)p.E + (size_t)crop * p.crop_stride;
   const int ntiles = (p.n_keys + TK - 1) / TK;
   float4v* xbuf = (float4v*)(smem + NS * TILE_B);          // [NW][2][64] partial score tiles
 
@@ -96,7 +191,7 @@ __global__ __launch_bounds__(128 * W) void cross_attn_kernel(CrossArgs p) {
     dma_off[j] = r * ROWB + c * 16;
   }
   auto issue = [&](int t, int slot) {
-    const char* src = Ec + (size_t)t * TILE_B;
+    const char* src = Ec + (size_t)t * p.tile_stride;
     char* dst = smem + slot * TILE_B;
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
@@ -137,78 +232,25 @@ __global__ __launch_bounds__(128 * W) void cross_attn_kernel(CrossArgs p) {
   for (int i = 0; i < MT; ++i) acc[i] = (float4v){0.f, 0.f, 0.f, 0.f};
   float mref = 0.f, lsum = 0.f;
 
-  issue(0, 0);
-  if (NS == 3 && ntiles > 1) issue(1, 1);
+  constexpr int DEPTH = NS - 1;                // tiles issued ahead of the one being consumed
+  static_assert(NS >= 2 && DEPTH * NPW <= 60, "ring depth / vmcnt range");
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < ntiles) issue(i, i);
   int slot = 0;
   for (int t = 0; t < ntiles; ++t) {
     // tile t has landed once at most the DMA instructions of the tiles issued after it are outstanding
-    if (NS == 3 && t + 1 < ntiles) {
-      if (short_wave) wait_vm<(NPW > 1 ? NPW - 1 : 0)>();
-      else wait_vm<NPW>();
-    } else {
-      wait_vm<0>();
-    }
+    const int after = min(DEPTH - 1, ntiles - 1 - t);     // tiles issued after tile t
+    if (short_wave) wait_vm_dyn<NPW - 1, DEPTH - 1>(after);
+    else wait_vm_dyn<NPW, DEPTH - 1>(after);
     __builtin_amdgcn_s_barrier();
-    if (NS == 3) {
-      if (t + 2 < ntiles) issue(t + 2, slot == 0 ? 2 : slot - 1);   // the slot tile t - 1 occupied
-    } else if (t + 1 < ntiles) {
-      issue(t + 1, slot ^ 1);
-    }
-    const char* sb = smem + slot * TILE_B;
-    // ---- partial S^T[32 keys][16 heads] = E_tile[:, half] Qt[:, half]^T
-    float4v s[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const half8v a0 = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2));
-      const half8v a1 = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2) + 16 * ROWB);
-      s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, qf[ks], s[0], 0, 0, 0);
-      s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, qf[ks], s[1], 0, 0, 0);
-    }
-    // the other half's partial sums (same lane layout)
-    xbuf[(wave * 2 + 0) * 64 + lane] = s[0];
-    xbuf[(wave * 2 + 1) * 64 + lane] = s[1];
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the LDS writes above
-    __builtin_amdgcn_s_barrier();
-    s[0] += xbuf[((wave ^ 1) * 2 + 0) * 64 + lane];
-    s[1] += xbuf[((wave ^ 1) * 2 + 1) * 64 + lane];
-    // lane (n, g) holds head n, keys t*32 + 16 mt + 4 g + e.  Keys past the end: -inf.
-    const int key0 = t * TK;
-    if (key0 + TK > p.n_keys) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (key0 + 16 * mt + 4 * g + e >= p.n_keys) s[mt][e] = -INFINITY;
-    }
-    float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (t == 0) {
-      mref = mx;                                    // tile 0 always holds valid keys
-    } else if (__builtin_amdgcn_ballot_w64(mx > mref + 8.f) != 0) {   // stale reference: rescale only when a tile outgrows it
-      const float nr = fmaxf(mref, mx), f = __builtin_amdgcn_exp2f(mref - nr);
-      mref = nr;
-      lsum *= f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i] *= f;
-    }
-    half8v pf;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(s[mt][e] - mref);
-        lsum += pe;
-        pf[mt * 4 + e] = (_Float16)pe;
-      }
-    // ---- Ct^T[half of ED][16 heads] += E_tile[:, half]^T P^T
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const half4v lo = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3));
-      const half4v hi = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3) + 16 * ROWB);
-      const half8v a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf, acc[mt], 0, 0, 0);
-    }
+    // tile t + DEPTH goes into the slot tile t - 1 occupied (every wave is past its last read of it); cross_tile issues its DMA
+    // instructions between the MFMAs of the first product
+    const bool feed = t + DEPTH < ntiles;
+    const char* feed_src = Ec + (size_t)(t + DEPTH) * p.tile_stride;
+    char* feed_dst = smem + (slot == 0 ? NS - 1 : slot - 1) * TILE_B;
+    cross_tile<ED, W, NPW, NI>(smem + slot * TILE_B, feed_dst, xbuf, feed_src, feed, dma_off, a_off, t_off, qf, acc, mref, lsum, t,
+                               p.n_keys, wave, lane);
     slot = (slot == NS - 1) ? 0 : slot + 1;
   }
   lsum += __shfl_xor(lsum, 16);
@@ -226,80 +268,120 @@ __global__ __launch_bounds__(128 * W) void cross_attn_kernel(CrossArgs p) {
   }
 }
 
-// qt[r][h][d] = sum_j q[r][h*64 + j] wkt[h][d][j].  Computed transposed (rows of the output tile = dims, columns = 16 query
-// rows) so that a lane ends up with 4 consecutive dims of one (row, head): 8-byte stores.  grid (rows / 16, heads), 4 waves,
-// wave w = dims [w ED / 4, (w + 1) ED / 4).  log2(e) (the soft-max runs on exp2) is folded into wkt.
+// qt[r][h][d] = sum_j q[r][h*64 + j] wkt[h][d][j].  Computed transposed (rows of the MFMA tile = dims, columns = query rows) so
+// that a lane ends up with 4 consecutive dims of one (row, head).  grid (rows / 64, heads), 4 waves; wave w = dims
+// [w ED / 4, (w + 1) ED / 4) of all 64 rows: each W_k fragment it fetches (L2) serves 4 row tiles.  Results pass through a
+// wave-private LDS tile so that the stores are 16 bytes per lane, 128 contiguous bytes per row (the output, 94 MB per launch at
+// trocr-base sizes, is what bounds this kernel).  log2(e) (the soft-max runs on exp2) is folded into wkt.
 template <int ED>
 __global__ __launch_bounds__(256) void absorb_q_kernel(const _Float16* __restrict__ q, int ldq, const _Float16* __restrict__ wkt,
                                                       _Float16* __restrict__ qt, int rows) {
+  __shared__ __attribute__((aligned(16))) _Float16 stage[4][64][72];      // [wave][row][64 dims + pad]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, r = blockIdx.x * 16 + n;
-  half8v b[2];
+  const int h = blockIdx.y, r0 = blockIdx.x * 64;
+  half8v b[4][2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    if (r < rows) b[ks] = *(const half8v*)(q + (size_t)r * ldq + h * 64 + ks * 32 + g * 8);
-    else b[ks] = (half8v){0, 0, 0, 0, 0, 0, 0, 0};
-  }
-  constexpr int MTW = ED / 64;      // 16-dim tiles per wave
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r = r0 + nt * 16 + n;
+      if (r < rows) b[nt][ks] = *(const half8v*)(q + (size_t)r * ldq + h * 64 + ks * 32 + g * 8);
+      else b[nt][ks] = (half8v){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  constexpr int MTW = ED / 64;      // 16-dim tiles per wave (a multiple of 4)
   const _Float16* wrow = wkt + ((size_t)h * ED + wave * (ED / 4) + n) * 64 + g * 8;
-  _Float16* out = qt + ((size_t)r * 16 + h) * ED + wave * (ED / 4) + 4 * g;
-#pragma unroll 4
-  for (int mt = 0; mt < MTW; ++mt) {
-    const half8v a0 = *(const half8v*)(wrow + (size_t)mt * 16 * 64);
-    const half8v a1 = *(const half8v*)(wrow + (size_t)mt * 16 * 64 + 32);
-    float4v c = {0.f, 0.f, 0.f, 0.f};
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[1], c, 0, 0, 0);
-    if (r < rows) {
-      half4v o;
+#pragma unroll 1
+  for (int mg = 0; mg < MTW / 4; ++mg) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (_Float16)c[e];
-      *(half4v*)(out + mt * 16) = o;
+    for (int mi = 0; mi < 4; ++mi) {
+      const int mt = mg * 4 + mi;
+      const half8v a0 = *(const half8v*)(wrow + (size_t)mt * 16 * 64);
+      const half8v a1 = *(const half8v*)(wrow + (size_t)mt * 16 * 64 + 32);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        float4v c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[nt][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[nt][1], c, 0, 0, 0);
+        half4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (_Float16)c[e];
+        *(half4v*)&stage[wave][nt * 16 + n][mi * 16 + 4 * g] = o;       // row nt*16+n, dims mi*16 + 4g .. +3 of this group
+      }
+    }
+    // 64 rows x 128 bytes -> 8 rows x 128 contiguous bytes per wave-instruction
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 8 + (lane >> 3), ch = lane & 7, r = r0 + row;
+      const uint4 v = *(const uint4*)&stage[wave][row][ch * 8];
+      if (r < rows) *(uint4*)(qt + ((size_t)r * 16 + h) * ED + wave * (ED / 4) + mg * 64 + ch * 8) = v;
     }
   }
 }
 
-// ao[r][h*64 + j] = sum_d ct[r][h][d] wv[h*64 + j][d] + bv[h*64 + j].  Transposed like absorb_q: output tile rows = j, columns =
-// 16 rows r.  grid (rows / 64, heads), 4 waves, wave w = rows [16 w, 16 w + 16) of the block.
+// ao[r][h*64 + j] = sum_d ct[r][h][d] wv[h*64 + j][d] + bv[h*64 + j].  Transposed like absorb_q: MFMA tile rows = j, columns =
+// query rows.  grid (rows / 64, heads), 4 waves: all four work on the same 64 rows (4 column tiles x 4 row tiles of
+// accumulators each) and split the contraction over ED four ways — four times the loads in flight of a one-wave-per-tile
+// layout, which is what this kernel needs: it streams the contexts (94 MB per launch) once and is latency-bound otherwise.  The
+// partial tiles are summed through LDS.
 template <int ED>
 __global__ __launch_bounds__(256) void absorb_v_kernel(const _Float16* __restrict__ ct, const _Float16* __restrict__ wv,
                                                       const float* __restrict__ bv, _Float16* __restrict__ ao, int ldo, int rows) {
+  __shared__ __attribute__((aligned(16))) float4v part[4][16][64];        // [wave][mt * 4 + nt][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, r = blockIdx.x * 64 + wave * 16 + n;
-  const _Float16* brow = ct + ((size_t)min(r, rows - 1) * 16 + h) * ED + g * 8;
-  const _Float16* arow = wv + ((size_t)h * 64 + n) * ED + g * 8;
-  float4v c[4];
+  const int h = blockIdx.y, r0 = blockIdx.x * 64;
+  constexpr int KSW = ED / 32 / 4;                 // k-steps per wave
+  const _Float16* brow[4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) c[mt] = (float4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int ks = 0; ks < ED / 32; ++ks) {
-    const half8v b = *(const half8v*)(brow + ks * 32);
+  for (int nt = 0; nt < 4; ++nt) brow[nt] = ct + ((size_t)min(r0 + nt * 16 + n, rows - 1) * 16 + h) * ED + wave * (ED / 4) + g * 8;
+  const _Float16* arow = wv + ((size_t)h * 64 + n) * ED + wave * (ED / 4) + g * 8;
+  float4v c[4][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const half8v a = *(const half8v*)(arow + (size_t)mt * 16 * ED + ks * 32);
-      c[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c[mt], 0, 0, 0);
-    }
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) c[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int ks = 0; ks < KSW; ++ks) {
+    half8v a[4], b[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b[nt] = *(const half8v*)(brow[nt] + ks * 32);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a[mt] = *(const half8v*)(arow + (size_t)mt * 16 * ED + ks * 32);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) c[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[nt], c[mt][nt], 0, 0, 0);
   }
-  if (r >= rows) return;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) part[wave][mt * 4 + nt][lane] = c[mt][nt];
+  __syncthreads();
+  // wave w finishes row tile nt = w: sum of the four partials, bias, 8-byte stores
+  const int r = r0 + wave * 16 + n;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
+    float4v v = part[0][mt * 4 + wave][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += part[w][mt * 4 + wave][lane];
     const float4v bb = *(const float4v*)(bv + h * 64 + mt * 16 + 4 * g);
     half4v o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (_Float16)(c[mt][e] + bb[e]);
-    *(half4v*)(ao + (size_t)r * ldo + h * 64 + mt * 16 + 4 * g) = o;
+    for (int e = 0; e < 4; ++e) o[e] = (_Float16)(v[e] + bb[e]);
+    if (r < rows) *(half4v*)(ao + (size_t)r * ldo + h * 64 + mt * 16 + 4 * g) = o;
   }
 }
 
 template <int ED>
 int launch_ed(mhip_ctx* ctx, const CrossAbsorbDesc& d) {
   const int rows = d.crops * d.beam;
-  PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL((absorb_q_kernel<ED>), dim3((rows + 15) / 16, d.heads), dim3(256), 0, ctx->stream,
+  PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL((absorb_q_kernel<ED>), dim3((rows + 63) / 64, d.heads), dim3(256), 0, ctx->stream,
                                                      (const _Float16*)d.q, d.ldq, (const _Float16*)d.wkt, (_Float16*)d.qt, rows));
   CrossArgs a;
   a.E = (const _Float16*)d.E; a.qt = (const _Float16*)d.qt; a.ct = (_Float16*)d.ct;
-  a.kv_rows = d.kv_rows; a.n_keys = d.n_keys; a.heads = d.heads;
   constexpr int TILE_B = TK * ED * 2;
+  a.n_keys = d.n_keys; a.heads = d.heads;
+  if (d.tiled) { a.crop_stride = TILE_B; a.tile_stride = (size_t)d.crops * TILE_B; }
+  else { a.crop_stride = (size_t)d.kv_rows * ED * 2; a.tile_stride = TILE_B; }
   const size_t lds = (size_t)cross_slots(ED, d.beam) * TILE_B + (size_t)d.beam * 4096;
 #define CROSS_LAUNCH(WV)                                                                                                       \
   do {                                                                                                                         \
