@@ -6,7 +6,7 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Default workload ``dit_trocr`` = BASELINE configs[2], the configuration the pages/sec metric is quoted on: DiT-base
-Mask R-CNN detector + TrOCR-base recognizer on 2550x3300 pages resident in HBM.  One *step* = ``--pages`` pages per GPU:
+Mask R-CNN detector + TrOCR-base recognizer on 2550x3300 pages resident in HBM.  One *step* = ``--pages`` (64) pages per GPU:
     Pillow-exact bilinear resize to 1035x800 -> DiT-base backbone + FPN + RPN + ROI heads + FastRCNN inference
     (one detector pass: bbox_refinement=False) -> boxes to the host;
     40 ground-truth line boxes per page (fixed recognizer work, SURVEY.md section 8d "headline") -> Pillow-exact bicubic to
@@ -702,12 +702,12 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
             bp._detect_batch = fixed
         return bp
 
-    tp = TrOcrProcessor(trocr_model=rec, batch_size=P * LINES_PER_PAGE)
+    tp = TrOcrProcessor(trocr_model=rec, batch_size=min(P, 32) * LINES_PER_PAGE)
     out = {}
     for name, fixed, refine, n_pages in (("fixed_lines", True, False, P), ("detector_driven", False, False, min(P, 8)),
                                          ("detector_driven_refinement", False, True, min(P, 8))):
         eng = MarieHipOcrEngine(box_processor=make_box(fixed, refine), default_ocr_processor=tp)
-        eng.page_batch = P
+        eng.page_batch = min(P, 32)       # two batches at 64 pages: the detector of the second runs under the recognizer of the first
         fr = frames[:n_pages]
         reps = 2 if fixed else 1
         if fixed:
@@ -750,7 +750,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["dit_trocr", "craft_crnn", "pages", "crnn"], default="dit_trocr")
-    ap.add_argument("--pages", type=int, default=0, help="pages per GPU per step (default: 32 dit_trocr, 12 craft_crnn)")
+    ap.add_argument("--pages", type=int, default=0, help="pages per GPU per step (default: 64 dit_trocr = BASELINE configs[2], 12 craft_crnn)")
     ap.add_argument("--det-batch", type=int, default=8, help="pages per detector forward (dit_trocr)")
     ap.add_argument("--decode-len", type=int, default=15, help="generated tokens before the forced EOS (dit_trocr)")
     ap.add_argument("--model", choices=["base", "large"], default="base", help="DiT detector size (dit_trocr)")
@@ -783,7 +783,7 @@ def main():
     if args.workload == "pages":
         args.workload = "craft_crnn"
     if args.pages <= 0:
-        args.pages = 32 if args.workload == "dit_trocr" else 12
+        args.pages = 64 if args.workload == "dit_trocr" else 12       # BASELINE configs[2]: 64 pages
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
