@@ -310,6 +310,25 @@ int mhip_roi_align_host(mhip_ctx* ctx, const float* const* feats_host, const int
 int mhip_det_final_host(mhip_ctx* ctx, const float* head_host, const float* rois_host, int n, int img_h, int img_w,
                         int page_h, int page_w, float score_thresh, float nms_thresh, int max_det, float* boxes_out,
                         float* scores_out, int* count_out);
+/* ---- overlay cleaner: pix2pixHD LocalEnhancer generator + blend -------------------------------- */
+/* replaces: OverlayProcessor.__extract_segmentation_mask / model.test() (marie/overlay/overlay.py:165-189;
+ * marie/models/pix2pix/models/networks_hd.py:24-213, netG "local", instance norm, spectral-normed convolutions) — page in HBM
+ * -> generator -> image in HBM, no PNG round trip.  ngf: base width (64 in the reference; f16 needs a multiple of 64, f32 32). */
+typedef struct mhip_overlay mhip_overlay;
+int mhip_overlay_create(mhip_ctx* ctx, int precision, int ngf, mhip_overlay** out);
+int mhip_overlay_destroy(mhip_overlay* m);
+/* state_dict keys of the reference's netG ("model.1.weight_orig" / ".weight_u" / ".weight_v" / ".bias", "model1_2.3.*",
+ * "downsample.weight" ...; an optional "netG." / "module." prefix is ignored); data fp32 in the checkpoint's layout            */
+int mhip_overlay_set_tensor(mhip_overlay* m, const char* key, const float* data, const int64_t* shape, int ndim);
+int mhip_overlay_finalize(mhip_overlay* m);
+/* OverlayProcessor.preprocess (overlay.py:147-163): the white canvas the page is placed on (both sides to the next multiple of
+ * 32 when either is ragged)                                                                                                    */
+int mhip_overlay_padded_shape(int h, int w, int* H, int* W);
+/* page u8 BGR [h][w][3] (device) -> the generator's image u8 RGB [H][W][3] on the padded canvas = tensor2im(fake)             */
+int mhip_overlay_forward(mhip_overlay* m, const uint8_t* page_dev, int h, int w, uint8_t* fake_rgb_dev);
+int mhip_overlay_forward_host(mhip_overlay* m, const uint8_t* page_host, int h, int w, uint8_t* fake_rgb_host, float* raw_host);
+/* replaces: OverlayProcessor.blend_to_text (overlay.py:247-291): real BGR + generator image -> text-only image (BGR)          */
+int mhip_overlay_blend(mhip_ctx* ctx, const uint8_t* real_bgr_dev, const uint8_t* mask_dev, uint8_t* out_dev, size_t pixels);
 /* replaces: blackout_bboxes, marie/boxes/dit/ulim_dit_box_processor.py:161-198, in place on a device page (BGR).        */
 int mhip_blackout_bboxes(mhip_ctx* ctx, uint8_t* page_dev, int h, int w, const int32_t* boxes_xyxy_host, int n,
                          int* changed);

@@ -84,6 +84,14 @@ _SIGNATURES = (
     ("mhip_roi_align_host", _i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     ("mhip_det_final_host", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, _i, _vp, _vp, _vp]),
     ("mhip_blackout_bboxes", _i, [_vp, _vp, _i, _i, _vp, _i, C.POINTER(_i)]),
+    ("mhip_overlay_create", _i, [_vp, _i, _i, C.POINTER(_vp)]),
+    ("mhip_overlay_destroy", _i, [_vp]),
+    ("mhip_overlay_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
+    ("mhip_overlay_finalize", _i, [_vp]),
+    ("mhip_overlay_padded_shape", _i, [_i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    ("mhip_overlay_forward", _i, [_vp, _vp, _i, _i, _vp]),
+    ("mhip_overlay_forward_host", _i, [_vp, _vp, _i, _i, _vp, _vp]),
+    ("mhip_overlay_blend", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("mhip_trocr_default_config", _i, [_i, _vp]),
     ("mhip_trocr_max_len", _i, [_vp]),
     ("mhip_trocr_create", _i, [_vp, _i, _vp, C.POINTER(_vp)]),

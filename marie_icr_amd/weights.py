@@ -556,3 +556,48 @@ def make_voting_case(seed: int, regions: bool):
             agg[name] = units
     reg = [{"id": 100 + u, "pageIndex": 0, "x": 0, "y": 0, "w": 50, "h": 20} for u in range(n_units)] if regions else None
     return names, agg, reg
+
+
+# ------------------------------------------------------------------------------------------------ overlay (pix2pixHD LocalEnhancer)
+def overlay_conv_table(ngf: int = 64):
+    """(state_dict prefix, kind, out channels, in channels, kernel) of every convolution of the reference's ``LocalEnhancer``
+    generator (marie/models/pix2pix/models/networks_hd.py:24-106 with n_downsample_global 3, n_blocks_global 9,
+    n_local_enhancers 1, n_blocks_local 3 — networks.py:189-196), in forward order.  kind: "sn" = spectral-normed Conv2d,
+    "snT" = spectral-normed ConvTranspose2d (weight laid out [in][out][k][k]), "plain" = Conv2d without spectral norm."""
+    G = 2 * ngf
+    t = [("downsample", "plain", 3, 3, 3), ("model.1", "sn", G, 3, 7), ("model.4", "sn", 2 * G, G, 3),
+         ("model.7", "sn", 4 * G, 2 * G, 3), ("model.10", "sn", 8 * G, 4 * G, 3)]
+    for b in range(9):
+        t += [(f"model.{13 + b}.conv_block.1", "sn", 8 * G, 8 * G, 3), (f"model.{13 + b}.conv_block.5", "sn", 8 * G, 8 * G, 3)]
+    t += [("model.23", "sn", 4 * G, 8 * G, 3), ("model.26", "sn", 2 * G, 4 * G, 3), ("model.29", "sn", G, 2 * G, 3),
+          ("model1_1.1", "sn", ngf, 3, 7), ("model1_1.4", "sn", 2 * ngf, ngf, 3)]
+    for b in range(3):
+        t += [(f"model1_2.{b}.conv_block.1", "sn", 2 * ngf, 2 * ngf, 3), (f"model1_2.{b}.conv_block.5", "sn", 2 * ngf, 2 * ngf, 3)]
+    t += [("model1_2.3", "snT", ngf, 2 * ngf, 3), ("model1_2.7", "sn", 3, ngf, 7)]
+    return t
+
+
+def make_overlay_state(seed: int = 0, ngf: int = 64) -> Dict[str, np.ndarray]:
+    """Seeded weights for the overlay generator under the reference's state_dict keys: ``weight_orig`` / ``weight_u`` /
+    ``weight_v`` / ``bias`` per spectral-normed layer.  ``u`` and ``v`` come from ten power iterations, as in a trained
+    checkpoint (at inference the layer divides ``weight_orig`` by u^T W v, torch.nn.utils.spectral_norm in eval mode)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    st = {}
+    for name, kind, co, ci, k in overlay_conv_table(ngf):
+        shape = (ci, co, k, k) if kind == "snT" else (co, ci, k, k)
+        w = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32) * np.float32(np.sqrt(3.0 / (ci * k * k)))
+        b = rng.uniform(-0.2, 0.2, size=(co,)).astype(np.float32)
+        if kind == "plain":
+            st[name + ".weight"], st[name + ".bias"] = w, b
+            continue
+        mat = (w.transpose(1, 0, 2, 3) if kind == "snT" else w).reshape(co, -1).astype(np.float64)   # dim = 1 for ConvTranspose
+        u = rng.normal(size=(co,))
+        u /= np.linalg.norm(u)
+        for _ in range(10):
+            v = mat.T @ u
+            v /= np.linalg.norm(v) + 1e-12
+            u = mat @ v
+            u /= np.linalg.norm(u) + 1e-12
+        st[name + ".weight_orig"], st[name + ".bias"] = w, b
+        st[name + ".weight_u"], st[name + ".weight_v"] = u.astype(np.float32), v.astype(np.float32)
+    return st

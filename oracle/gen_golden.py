@@ -447,9 +447,58 @@ def gen_voting(out_dir):
     print("voting", len(cases), sum(len(json.dumps(c)) for c in cases))
 
 
+def _load_ref_local_enhancer():
+    """marie/models/pix2pix/models/networks_hd.py (and the three pure-torch modules it imports: gausian.py, swish.py,
+    spectral_discriminator.py), unmodified, by path, as modules of a throw-away package."""
+    import importlib.util
+    import types
+
+    base = "/root/reference/marie/models/pix2pix/models/"
+    pkg = types.ModuleType("refpix")
+    pkg.__path__ = []
+    sys.modules["refpix"] = pkg
+    for name in ("gausian", "swish", "spectral_discriminator", "networks_hd"):
+        spec = importlib.util.spec_from_file_location("refpix." + name, base + name + ".py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules["refpix." + name] = m
+        spec.loader.exec_module(m)
+    return sys.modules["refpix.networks_hd"].LocalEnhancer
+
+
+def gen_overlay(out_dir):
+    """Outputs of the reference's own LocalEnhancer (netG 'local', instance norm: overlay.py:58-83, networks.py:189-196) for
+    seeded weights and images."""
+    import contextlib
+    import functools
+    import io
+
+    import torch.nn as nn
+
+    from marie_icr_amd.weights import make_image_u8, make_overlay_state
+
+    LocalEnhancer = _load_ref_local_enhancer()
+    norm = functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=False)
+    for tag, ngf, (h, w), wseed, iseed in (("ngf32", 32, (64, 96), 0, 3), ("ngf64", 64, (64, 64), 1, 4)):
+        with contextlib.redirect_stdout(io.StringIO()):              # the constructor prints a channel count
+            net = LocalEnhancer(3, 3, ngf, 3, 9, 1, 3, norm)
+        st = make_overlay_state(wseed, ngf)
+        missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+        net.eval()
+        img = make_image_u8(iseed, 1, h, w)[0]                         # RGB order here; the product is fed the BGR-reversed frame
+        x = ((torch.from_numpy(img.astype(np.float32) / np.float32(255.0)) - 0.5) / 0.5).permute(2, 0, 1).unsqueeze(0)
+        with torch.no_grad():
+            y = net(x)[0].permute(1, 2, 0).numpy()
+        np.savez_compressed(os.path.join(out_dir, f"overlay_{tag}.npz"), weight_seed=wseed, image_seed=iseed, ngf=ngf,
+                            hw=np.asarray([h, w]), weight_sha256=state_checksum(st), out=y.astype(np.float32))
+        print("overlay", tag, y.shape, float(np.abs(y).max()), float(np.abs(y).mean()), missing)
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if "--overlay-only" in sys.argv:
+        gen_overlay(out_dir)
+        return
     if "--voting-only" in sys.argv:
         gen_voting(out_dir)
         return
