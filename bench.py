@@ -499,9 +499,10 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    engine = None
+    engine = overlay = None
     if world == 1 and not args.no_secondary:
         engine = run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt)
+        overlay = run_overlay_leg(args, torch, ctxs[0], pages, prec)
     if rank != 0:
         return
     rate = world * P * args.steps / dt
@@ -568,6 +569,8 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
         out["mixed_dpi"] = mixed
     if engine is not None:
         out["engine_api"] = engine
+    if overlay is not None:
+        out["overlay"] = overlay
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = cpu_baseline_dit_trocr(dit_state, trocr_state, dims, args.decode_len,
                                                                     LINES_PER_PAGE, det, rec, args.precision)
@@ -676,6 +679,42 @@ def run_mixed_dpi(args, torch, dist, rank, world, det, rec, ctxs, streams, fence
                       "chunk pooled into one recognizer batch; f16", "pages": total, "seconds": ds, "value": total / ds,
             "unit": "pages/s", "scaling": "strong", "chunks_this_rank": len(mine), "sizes_hw": [list(s) for s in MIXED_DPI_SIZES],
             "result_checksum": _checksum(allrec)}
+
+
+def run_overlay_leg(args, torch, ctx, pages, prec):
+    """SURVEY.md 8(f) row 3, the step before the path: the overlay cleaner's generator (pix2pixHD LocalEnhancer, ngf 64, seeded
+    weights) on the same resident 2550 x 3300 pages — page in HBM -> generator -> image in HBM."""
+    import ctypes as C
+
+    from marie_icr_amd.overlay import OverlayModel
+    from marie_icr_amd.weights import make_overlay_state
+
+    m = OverlayModel(ctx, make_overlay_state(0, 64), 64, prec)
+    H, W = m.padded_shape(PAGE_H, PAGE_W)
+    fake = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    page_bytes = PAGE_H * PAGE_W * 3
+    n = 3
+    m.forward_device(pages.data_ptr(), PAGE_H, PAGE_W, fake.data_ptr())          # warm-up (workspace growth)
+    torch.cuda.synchronize()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(n):
+        m.forward_device(pages.data_ptr() + (i % len(pages)) * page_bytes, PAGE_H, PAGE_W, fake.data_ptr())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    k = prof["conv_igemm"]
+    m.close()
+    peak = PEAK_MFMA_TFLOPS_F16 if args.precision == "f16" else PEAK_MFMA_TFLOPS_F32
+    tf = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
+    return {"value": n / dt, "unit": "pages/s", "ms_per_page": 1e3 * dt / n, "canvas_hw": [H, W],
+            "conv_igemm": {"gflop_per_page": k["flops"] / 1e9 / n, "ms_per_page": k["total_ms"] / n, "tflops": tf, "frac": tf / peak},
+            "kernels_ms_per_page": {name: v["total_ms"] / n for name, v in prof.items() if v["launches"] and name not in IGEMM_VARIANTS},
+            "what": "OverlayProcessor's generator alone (netG local, ngf 64, instance norm), one page per forward as in the "
+                    "reference (batch_size 1), page resident in HBM; FLOPs as launched (stride-2 convolutions at full width, the "
+                    "transposed convolution over a zero-inserted image)"}
 
 
 def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
