@@ -12,7 +12,8 @@
 // Every convolution with >= 32 input channels runs on conv_igemm (MFMA): reflection padding is an explicit padded copy, a
 // stride-2 convolution is computed at full width with vertical stride 2 and the InstanceNorm pass reads its even columns, the
 // transposed convolution is a 3x3 convolution (flipped weights) over a zero-inserted image.  Spectral normalisation
-// (weight_orig / u^T W v, eval mode) is folded into the packed weights.  The two 3-channel stems use a direct kernel.
+// (weight_orig / u^T W v, eval mode) is folded into the packed weights.  The two 7x7 stems over the 3-channel image are GEMMs
+// over an explicit [pixels][192] patch matrix (147 taps, zero-filled to 192); the 3 -> 3 input down-sampler is a direct kernel.
 #include <math.h>
 
 #include <string>
@@ -24,6 +25,7 @@ int mhip_ov_preprocess(mhip_ctx* ctx, int prec, const uint8_t* page, int h, int 
 int mhip_ov_conv_c3(mhip_ctx* ctx, int prec, const void* in, const float* wt, const float* bias, void* out, int H, int W, int cout, int K,
                     int stride, int pad, int refl);
 int mhip_ov_reflect_pad(mhip_ctx* ctx, int prec, const void* in, void* out, int H, int W, int C, int p);
+int mhip_ov_im2col7(mhip_ctx* ctx, int prec, const void* in, void* out, int H, int W);
 int mhip_ov_instance_norm(mhip_ctx* ctx, int prec, const void* x, int Ho, int Wfull, int cstep, int C, float eps, int swish,
                           const void* res, void* out, float* stats);
 int mhip_ov_upsample2x(mhip_ctx* ctx, int prec, const void* in, void* out, int H, int W, int C, int swish_in);
@@ -91,9 +93,8 @@ extern "C" int mhip_overlay_create(mhip_ctx* ctx, int precision, int ngf, mhip_o
   m->ctx = ctx; m->precision = precision; m->ngf = ngf;
   const size_t es = m->esz();
   for (const ConvSpec& s : conv_table(ngf)) {
-    const bool direct = s.ci == 3;
-    const int co_pad = s.co;
-    m->arena.take(s.name + "_w", direct ? (size_t)s.k * s.k * 3 * s.co * 4 : (size_t)co_pad * s.k * s.k * s.ci * es);
+    const bool direct = s.ci == 3 && s.k == 3, stem = s.ci == 3 && s.k == 7;       // stems: GEMM over a [pixels][192] patch matrix
+    m->arena.take(s.name + "_w", direct ? (size_t)s.k * s.k * 3 * s.co * 4 : (stem ? (size_t)s.co * 192 * es : (size_t)s.co * s.k * s.k * s.ci * es));
     m->arena.take(s.name + "_b", (size_t)s.co * 4);
   }
   *out = m;
@@ -152,7 +153,13 @@ extern "C" int mhip_overlay_finalize(mhip_overlay* m) {
       if (s.kind == 2) return w->data[((size_t)c * s.co + o) * kk + (s.k - 1 - ky) * s.k + (s.k - 1 - kx)] * inv;
       return w->data[((size_t)o * s.ci + c) * kk + ky * s.k + kx] * inv;
     };
-    if (s.ci == 3) {   // direct kernel: fp32 [tap][ci][co]
+    if (s.ci == 3 && s.k == 7) {   // stem: [co][192], k = tap * 3 + c, zero beyond 147
+      std::vector<float> tmp((size_t)s.co * 192, 0.f);
+      for (int o = 0; o < s.co; ++o)
+        for (int t = 0; t < kk; ++t)
+          for (int c = 0; c < 3; ++c) tmp[(size_t)o * 192 + t * 3 + c] = at(o, c, t / s.k, t % s.k);
+      Arena::put(m->precision, a.h(s.name + "_w"), tmp.data(), tmp.size());
+    } else if (s.ci == 3) {   // direct kernel: fp32 [tap][ci][co]
       float* d = (float*)a.h(s.name + "_w");
       for (int t = 0; t < kk; ++t)
         for (int c = 0; c < 3; ++c)
@@ -185,7 +192,7 @@ static size_t overlay_ws_bytes(const mhip_overlay* m, int H, int W) {
   const size_t es = m->esz(), P = (size_t)H * W, ngf = m->ngf;
   // full resolution: x4, three ngf-channel maps (stem / padded copies / conv outputs) incl. the 6-pixel frame, zero-insert canvas,
   // output [P][8]; half resolution and below are bounded by the same again
-  size_t b = P * 4 * es + 4 * ((size_t)(H + 8) * (W + 8) * ngf * es) + P * 8 * es;
+  size_t b = P * 4 * es + 4 * ((size_t)(H + 8) * (W + 8) * ngf * es) + P * 8 * es + P * 192 * es;
   b += 8 * ((size_t)(H / 2 + 8) * (W / 2 + 8) * 2 * ngf * es);
   return 2 * b + (1 << 20);
 }
@@ -204,7 +211,7 @@ static int overlay_run(mhip_overlay* m, const uint8_t* page_dev, int h, int w, u
   if (rc) return rc;
   Carver ws(ctx->ws);
   const Arena& a = m->arena;
-  float* stats = ws.take<float>(2 * 2048 * 4);
+  float* stats = ws.take<float>(3 * 2048 * 4);
   const int Hh = H / 2, Wh = W / 2;
   // ---- input
   char* x4 = ws.take((size_t)H * W * 4 * es);
@@ -218,7 +225,16 @@ static int overlay_run(mhip_overlay* m, const uint8_t* page_dev, int h, int w, u
   char* t1 = ws.take(gmax);
   char* t2 = ws.take(gmax);
   // ---- global branch
-  if ((rc = mhip_ov_conv_c3(ctx, prec, half4, a.d<float>("model.1_w"), a.d<float>("model.1_b"), t1, Hh, Wh, G, 7, 1, 3, 1))) return rc;
+  auto stem = [&](const void* img4, const char* name, void* out, int hs, int wsz, int cout, void* patches) -> int {
+    int r = mhip_ov_im2col7(ctx, prec, img4, patches, hs, wsz);
+    if (r) return r;
+    ConvDesc c;
+    c.in = patches; c.w = a.d(std::string(name) + "_w"); c.bias = a.d<float>(std::string(name) + "_b"); c.out = out;
+    c.B = 1; c.H = hs; c.W = wsz; c.Cin = 192; c.KH = c.KW = 1; c.pad = 0; c.N = cout;
+    return mhip_launch_conv_igemm(ctx, prec, c);
+  };
+  char* patches = ws.take((size_t)H * W * 192 * es);
+  if ((rc = stem(half4, "model.1", t1, Hh, Wh, G, patches))) return rc;
   if ((rc = mhip_ov_instance_norm(ctx, prec, t1, Hh, Wh, 1, G, IN_EPS, 1, nullptr, g, stats))) return rc;
   int ch = G, hh = Hh, wh = Wh;
   for (const char* n : {"model.4", "model.7", "model.10"}) {
@@ -251,7 +267,7 @@ static int overlay_run(mhip_overlay* m, const uint8_t* page_dev, int h, int w, u
   const size_t lmax = (size_t)(H + 6) * (W + 6) * ngf * es;
   char* l1 = ws.take(lmax);
   char* l2 = ws.take(lmax);
-  if ((rc = mhip_ov_conv_c3(ctx, prec, x4, a.d<float>("model1_1.1_w"), a.d<float>("model1_1.1_b"), l1, H, W, ngf, 7, 1, 3, 1))) return rc;
+  if ((rc = stem(x4, "model1_1.1", l1, H, W, ngf, patches))) return rc;
   if ((rc = mhip_ov_instance_norm(ctx, prec, l1, H, W, 1, ngf, IN_EPS, 1, nullptr, l1, stats))) return rc;
   if ((rc = conv(m, l1, "model1_1.4", l2, H, W, ngf, G, 3, 1, 2))) return rc;                                 // [Hh][W][G]
   if ((rc = mhip_ov_instance_norm(ctx, prec, l2, Hh, W, 2, G, IN_EPS, 1, nullptr, t1, stats))) return rc;     // [Hh][Wh][G]

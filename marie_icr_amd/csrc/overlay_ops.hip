@@ -7,6 +7,8 @@
 // Activations are NHWC; every kernel here is HBM-bound element-wise / reduction work: 16-byte chunks per lane, one pass.
 #include <math.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -106,6 +108,28 @@ __global__ __launch_bounds__(256) void ov_conv_c3_kernel(const T* __restrict__ i
   for (int c = 0; c < CG; ++c) o[c] = (T)acc[c];
 }
 
+// 7x7 stems on the matrix cores: patch matrix [H*W][192] (k = (ky*7 + kx)*3 + c for the 147 taps, zeros up to 192) of the
+// reflection-padded 3-channel image; the convolution is then a GEMM with K = 192.  One thread = 8 consecutive k of one pixel.
+template <typename T>
+__global__ void ov_im2col7_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)H * W * 24) return;
+  const int j = (int)(idx % 24);
+  const size_t px = idx / 24;
+  const int y = (int)(px / W), x = (int)(px - (size_t)y * W);
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = j * 8 + e;
+    f[e] = 0.f;
+    if (k < 147) {
+      const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+      f[e] = (float)in[((size_t)reflect(y + ky - 3, H) * W + reflect(x + kx - 3, W)) * 4 + c];
+    }
+  }
+  Chunk<T>::store(out + idx * 8, f);
+}
+
 // out[(y, x)] = in[reflect(y - p), reflect(x - p)], 8 channels per thread
 template <typename T>
 __global__ void ov_reflect_pad_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int C8, int p) {
@@ -121,38 +145,40 @@ __global__ void ov_reflect_pad_kernel(const T* __restrict__ in, T* __restrict__ 
   Chunk<T>::store(out + idx * 8, f);
 }
 
-// Per-channel sums over the pixels (y, xo * cstep), xo < Wo of x [Ho][Wfull][C]: MODE 0 sum x, MODE 1 sum (x - mean)^2
-// (mean = sum0 / P read from `stats`).  256 pixels per workgroup; partials reduced through LDS, one atomicAdd per channel.
-template <typename T, int MODE>
+// Per-channel statistics over the pixels (y, xo * cstep), xo < Wo of x [Ho][Wfull][C] in ONE pass: with k[c] = the channel's value
+// at pixel 0 (a shift that keeps the sums small next to the spread), stats[c] += sum (x - k), stats[C + c] += sum (x - k)^2,
+// stats[2 C + c] = k.  A grid-strided walk of at most 2048 workgroups: partials reduced through LDS, one atomicAdd per channel
+// and workgroup (one per 256 pixels was 33 k atomics per address at full resolution: 75 ms per page).
+template <typename T>
 __global__ __launch_bounds__(256) void ov_colsum_kernel(const T* __restrict__ x, int Wfull, int Wo, int cstep, int C, long long P,
                                                        float* __restrict__ stats) {
-  __shared__ float red[256 * 8];
+  __shared__ float red[256 * 16];
   const int C8 = C >> 3;
   const int lanes_p = 256 / C8 > 0 ? 256 / C8 : 1;        // C <= 2048
   const int cc = threadIdx.x % C8, lp = threadIdx.x / C8;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float mean[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (MODE == 1 && lp < lanes_p)
+  float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, k[8];
+  if (lp < lanes_p) {
+    Chunk<T>::load(x + (size_t)cc * 8, k);
+    if (blockIdx.x == 0 && lp == 0)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mean[i] = stats[cc * 8 + i] / (float)P;
-  const long long p0 = (long long)blockIdx.x * 256;
-  if (lp < lanes_p)
-    for (long long p = p0 + lp; p < p0 + 256 && p < P; p += lanes_p) {
+      for (int i = 0; i < 8; ++i) stats[2 * C + cc * 8 + i] = k[i];
+    for (long long p = (long long)blockIdx.x * lanes_p + lp; p < P; p += (long long)gridDim.x * lanes_p) {
       const long long y = p / Wo, xo = p - y * Wo;
       float f[8];
       Chunk<T>::load(x + ((size_t)(y * Wfull + xo * cstep) * C8 + cc) * 8, f);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s[i] += MODE == 0 ? f[i] : (f[i] - mean[i]) * (f[i] - mean[i]);
+      for (int i = 0; i < 8; ++i) { const float d = f[i] - k[i]; s1[i] += d; s2[i] += d * d; }
     }
+  }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = s[i];
+  for (int i = 0; i < 8; ++i) { red[threadIdx.x * 16 + i] = s1[i]; red[threadIdx.x * 16 + 8 + i] = s2[i]; }
   __syncthreads();
   if (lp == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 16; ++i) {
       float t = 0.f;
-      for (int l = 0; l < lanes_p; ++l) t += red[(l * C8 + cc) * 8 + i];
-      atomicAdd(stats + (MODE == 0 ? 0 : C) + cc * 8 + i, t);
+      for (int l = 0; l < lanes_p; ++l) t += red[(l * C8 + cc) * 16 + i];
+      atomicAdd(stats + (i < 8 ? 0 : C) + cc * 8 + (i & 7), t);
     }
   }
 }
@@ -171,8 +197,8 @@ __global__ void ov_in_apply_kernel(const T* __restrict__ x, int Wfull, int Wo, i
   if (res) Chunk<T>::load(res + idx * 8, r);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float mean = stats[cc * 8 + i] / (float)P, var = stats[C + cc * 8 + i] / (float)P;
-    float v = (f[i] - mean) * (1.f / sqrtf(var + eps));
+    const float m1 = stats[cc * 8 + i] / (float)P, var = fmaxf(stats[C + cc * 8 + i] / (float)P - m1 * m1, 0.f);
+    float v = (f[i] - (stats[2 * C + cc * 8 + i] + m1)) * (1.f / sqrtf(var + eps));
     if (act) v = swishf(v);
     if (res) v += r[i];
     f[i] = v;
@@ -321,6 +347,15 @@ int mhip_ov_conv_c3(mhip_ctx* ctx, int prec, const void* in, const float* wt, co
 #undef C3
 }
 
+int mhip_ov_im2col7(mhip_ctx* ctx, int prec, const void* in, void* out, int H, int W) {
+  if (H < 4 || W < 4) return mhip_fail(ctx, MHIP_EINVAL, "ov_im2col7: image smaller than the reflection frame");
+  const size_t n = (size_t)H * W * 24;
+  return run(ctx, "ov_im2col7", [&] {
+    if (prec == MHIP_PREC_F16) hipLaunchKernelGGL((ov_im2col7_kernel<_Float16>), dim3(blocks(n)), dim3(256), 0, ctx->stream, (const _Float16*)in, (_Float16*)out, H, W);
+    else hipLaunchKernelGGL((ov_im2col7_kernel<float>), dim3(blocks(n)), dim3(256), 0, ctx->stream, (const float*)in, (float*)out, H, W);
+  });
+}
+
 #define OV_T(prec, KERNEL, GRID, ...)                                                                                           \
   do {                                                                                                                          \
     if ((prec) == MHIP_PREC_F16) hipLaunchKernelGGL((KERNEL<_Float16>), dim3(GRID), dim3(256), 0, ctx->stream, __VA_ARGS__);   \
@@ -337,21 +372,17 @@ int mhip_ov_reflect_pad(mhip_ctx* ctx, int prec, const void* in, void* out, int 
 }
 
 // InstanceNorm2d(affine=False, eps) [+ swish] [+ residual] over the pixels (y, xo * cstep) of x [Ho][Wfull][C] -> out [Ho][Wfull/cstep][C].
-// stats: 2 C floats of scratch.
+// stats: 3 C floats of scratch.
 int mhip_ov_instance_norm(mhip_ctx* ctx, int prec, const void* x, int Ho, int Wfull, int cstep, int C, float eps, int swish,
                           const void* res, void* out, float* stats) {
   if (C % 8 || C > 2048 || cstep < 1 || Wfull % cstep) return mhip_fail(ctx, MHIP_EINVAL, "ov_instance_norm: bad shape");
   const int Wo = Wfull / cstep;
   const long long P = (long long)Ho * Wo;
   MHIP_HIP(ctx, hipMemsetAsync(stats, 0, (size_t)2 * C * 4, ctx->stream));
+  const unsigned sgrid = (unsigned)std::min<size_t>(blocks((size_t)P), 2048);
   int rc = run(ctx, "ov_colsum", [&] {
-    if (prec == MHIP_PREC_F16) hipLaunchKernelGGL((ov_colsum_kernel<_Float16, 0>), dim3(blocks((size_t)P)), dim3(256), 0, ctx->stream, (const _Float16*)x, Wfull, Wo, cstep, C, P, stats);
-    else hipLaunchKernelGGL((ov_colsum_kernel<float, 0>), dim3(blocks((size_t)P)), dim3(256), 0, ctx->stream, (const float*)x, Wfull, Wo, cstep, C, P, stats);
-  });
-  if (rc) return rc;
-  rc = run(ctx, "ov_colsum2", [&] {
-    if (prec == MHIP_PREC_F16) hipLaunchKernelGGL((ov_colsum_kernel<_Float16, 1>), dim3(blocks((size_t)P)), dim3(256), 0, ctx->stream, (const _Float16*)x, Wfull, Wo, cstep, C, P, stats);
-    else hipLaunchKernelGGL((ov_colsum_kernel<float, 1>), dim3(blocks((size_t)P)), dim3(256), 0, ctx->stream, (const float*)x, Wfull, Wo, cstep, C, P, stats);
+    if (prec == MHIP_PREC_F16) hipLaunchKernelGGL((ov_colsum_kernel<_Float16>), dim3(sgrid), dim3(256), 0, ctx->stream, (const _Float16*)x, Wfull, Wo, cstep, C, P, stats);
+    else hipLaunchKernelGGL((ov_colsum_kernel<float>), dim3(sgrid), dim3(256), 0, ctx->stream, (const float*)x, Wfull, Wo, cstep, C, P, stats);
   });
   if (rc) return rc;
   const size_t n = (size_t)P * (C / 8);
