@@ -48,20 +48,13 @@ namespace {
 //             (decoder steps: M = crops x beams) that the big tiles would leave most of the 256 CUs idle.
 template <int BN_>
 struct Cfg {
-  static constexpr bool SMALL = BN_ > 1000;
+  static constexpr bool SMALL = BN_ / 1000 == 1;
   static constexpr int BN = BN_ % 1000;
   static constexpr int BM = SMALL ? 128 : ((BN == 64) ? 512 : 256);
   static constexpr int WN = BN / 64;             // waves along N
   static constexpr int WM = 8 / WN;              // waves along M
   static constexpr int MT = BM / WM / 16;        // 16-row MFMA tiles per wave along M (4 or 8)
-#ifdef IGEMM_KSPLIT
-  // Explored variant (N tile 256): each K slice staged as two 64-byte half-rows (k-groups) in a 4-slot ring of 32 KiB
-  // half-slices, so three half-slices (96 KiB) are in flight and a k-group's MFMAs start as soon as ITS half has
-  // landed.  Measured 8-10 % SLOWER than the 2-slot whole-slice ring (twice the barriers; profiles/r01/h_*): off.
-  static constexpr bool KSPLIT = (BN == 256);
-#else
   static constexpr bool KSPLIT = false;
-#endif
   static constexpr int NSTAGE = (KSPLIT || SMALL) ? 4 : ((BN == 128) ? 3 : 2);
   static constexpr int HROWB = KSPLIT ? 64 : ROWB;        // bytes of one staged row
   static constexpr int A_BYTES = BM * HROWB;
@@ -135,11 +128,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     nt = L % p.ntiles;
     mt = L / p.ntiles;
   }
-#ifdef IGEMM_DBG_HOT     // measurement aid (profiles/r01/o_*): every tile reads the same few A / W tiles (L2-resident); timing only
-  const int m0 = (mt & 3) * BM, n0 = (nt & 1) * C::BN;
-#else
   const int m0 = mt * BM, n0 = nt * C::BN;
-#endif
 
   // ---- staging set-up: each thread moves BM/64 A chunks + BN/64 W chunks per slice ---------
   // a wave-instruction covers RPI rows; a thread's q-th chunk sits RPI*8 rows further down
@@ -248,12 +237,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       else src = ok ? a_src[q] + a_off : p.zeros;
       glds16(src, la + q * RSTEP * C::HROWB);
     }
-#ifdef IGEMM_DBG_NO_W      // measurement aid: the W slice is staged for the first slice only (wrong results, timing only)
-    if (hs > 1) return;
-#endif
-#ifdef IGEMM_DBG_NO_A
-    (void)lb;
-#endif
 #pragma unroll
     for (int q = 0; q < C::WCHUNKS; ++q) {
       const char* src = w_src[q] ? w_src[q] + w_off : p.zeros;
@@ -289,29 +272,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 
   // ---- main loop: NSTAGE-slot ring, GL LDS-DMA instructions per wave per (half-)slice -------
   constexpr int D = C::NSTAGE - 1;  // (half-)slices in flight ahead of the one being computed
-#ifdef IGEMM_DBG_NO_LOOP   // measurement aid (profiles/r01/i_epilogue.txt): epilogue only
-  const int nsteps = 0;
-#else
   const int nsteps = C::KSPLIT ? 2 * p.nslices : p.nslices;
-#endif
   if (nsteps > 0) stage(0, 0);
   if (D > 1 && nsteps > 1) stage(1, 1);
   if (D > 2 && nsteps > 2) stage(2, 2);
-#ifdef IGEMM_DBG_CLOCK     // measurement aid (rule: the in-kernel clock is d(s_memtime) / d(s_memrealtime) x 100 MHz)
-  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
   int slot = 0, fill = D % C::NSTAGE;
-#ifdef IGEMM_DBG_CLOCK
-  unsigned long long dbg_ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define DBG_STAMP(k) do { if (it == nsteps / 2) dbg_ph[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define DBG_STAMP(k) do { } while (0)
-#endif
   for (int it = 0; it < nsteps; ++it) {
-#ifdef IGEMM_DBG_CLOCK
-    if (it == nsteps / 2 + 1) dbg_ph[8] = __builtin_amdgcn_s_memtime();
-#endif
-    DBG_STAMP(0);
     const int younger = min(D - 1, nsteps - 1 - it);   // (half-)slices issued after the one needed now
     if (C::GL == 6) {
       if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -324,17 +290,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       static_assert(D == 1 || C::GL == 6 || (C::GL == 4 && D == 3), "counted vmcnt table");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    DBG_STAMP(1);
     __builtin_amdgcn_s_barrier();
-    DBG_STAMP(2);
     const bool feed = it + D < nsteps;
-#ifndef IGEMM_NO_INTERLEAVE
     const bool interleave = pure && feed;   // plain GEMMs: the next slice's DMA instructions go between this slice's MFMAs
-#else
-    const bool interleave = false;
-#endif
     if (feed && !interleave) stage(it + D, fill);
-    DBG_STAMP(3);
     const char* sb = smem + slot * C::STAGE_BYTES;
 #pragma unroll
     for (int s = 0; s < (C::KSPLIT ? 1 : 2); ++s) {
@@ -343,22 +302,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       for (int t = 0; t < 4; ++t) b[t] = *(const chunk_t*)(sb + (b_off0[t] ^ (s << 6)));
 #pragma unroll
       for (int t = 0; t < MT; ++t) a[t] = *(const chunk_t*)(sb + (a_off0[t] ^ (s << 6)));
-#ifdef IGEMM_DBG_CLOCK
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (s == 0) DBG_STAMP(4); else DBG_STAMP(6);
-#endif
-#ifndef IGEMM_NO_SETPRIO
       __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster between the barriers (cdna guide T5)
-#endif
       // plain GEMM: one DMA instruction of the next slice in front of every IL_EVERY-th MFMA of the slice (counted over
       // both k-groups), so that the waves' demand on the vector-memory queue stays near what it drains (~33 cycles per
       // 1 KiB instruction per CU) and no wave sits in the queue with its MFMAs behind it; the last one is issued early
       // enough to land under the rest of the slice.  One MFMA sequence for both cases — only the DMA instructions sit
       // behind a uniform branch.
-#ifndef IGEMM_IL_EVERY
-#define IGEMM_IL_EVERY 4
-#endif
-      constexpr int NM = MT * 4, EVERY = C::KSPLIT ? (NM + C::GL - 1) / C::GL : ((MT == 8) ? IGEMM_IL_EVERY : (2 * NM + C::GL - 1) / C::GL / 2);
+      constexpr int NM = MT * 4, EVERY = C::KSPLIT ? (NM + C::GL - 1) / C::GL : ((MT == 8) ? 4 : (2 * NM + C::GL - 1) / C::GL / 2);
 #pragma unroll
       for (int idx = 0; idx < NM; ++idx) {
         const int gidx = s * NM + idx;                     // position in the slice's MFMA sequence
@@ -371,24 +321,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
 #pragma unroll
         for (int g = ((C::KSPLIT ? 1 : 2) * NM + EVERY - 1) / EVERY; g < C::GL; ++g) stage_pure_chunk(fill, g);   // left-overs
       }
-#ifndef IGEMM_NO_SETPRIO
       __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef IGEMM_DBG_CLOCK
-      if (s == 0) DBG_STAMP(5); else DBG_STAMP(7);
-#endif
     }
     slot = (slot == C::NSTAGE - 1) ? 0 : slot + 1;
     fill = (fill == C::NSTAGE - 1) ? 0 : fill + 1;
   }
 
-#ifdef IGEMM_DBG_CLOCK
-  const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime(), dbg_r1 = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef IGEMM_DBG_NO_EPI    // measurement aid: main loop only
-  if (acc[0][0][0] == 123.456f) *(float*)p.out = acc[1][1][1];
-  return;
-#endif
   // ---- epilogue: scale/bias, activation, in-register max-pool -> wave-private LDS transpose -> coalesced NHWC stores ----
   // Each wave transposes its own 16-row x 64-column MFMA row-tile through a private 4 KiB fp32 staging area: 16
   // conflict-free ds_write_b32 (one per accumulator value) and then 16-byte reads of 4 consecutive columns of one row,
@@ -583,14 +521,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   } else {
     if (gelu) body(N_{}, N_{}, Y{}, Y{}); else if (has_res) body(N_{}, Y{}, N_{}, Y{}); else body(N_{}, N_{}, N_{}, Y{});
   }
-#ifdef IGEMM_DBG_CLOCK     // corrupts 16 output bytes: timing builds only
-  if (blockIdx.x == gridDim.x / 2 && lane == 0) {      // every wave of one workgroup: absolute stamps of the middle slice
-    __builtin_amdgcn_s_sleep(64);
-    unsigned long long* o = (unsigned long long*)p.out;
-    if (wave == 0) { o[0] = dbg_t1 - dbg_t0; o[1] = dbg_r1 - dbg_r0; }
-    for (int k = 0; k < 9; ++k) o[2 + wave * 9 + k] = dbg_ph[k];
-  }
-#endif
 }
 
 template <typename T, int BN_>
