@@ -12,6 +12,7 @@ import sys
 from collections import defaultdict
 
 FAMILIES = (("conv_igemm", "conv_igemm_kernel"), ("conv3x3_patch", "conv3x3_patch"), ("attn_flash", "attn_flash"),
+            ("cross_attn", "cross_attn_kernel"), ("absorb_q", "absorb_q_kernel"), ("absorb_v", "absorb_v_kernel"),
             ("decode_attn", "decode_attn"), ("layernorm", "layernorm"), ("beam_candidates", "beam_candidates"))
 
 
@@ -35,7 +36,8 @@ def fold(path):
 def main():
     fetch, n1 = fold(sys.argv[1])
     write, n2 = fold(sys.argv[2])
-    out = {"units": "bytes", "fetch_correction": "FETCH_SIZE x 2 (gfx950, 16-byte-per-lane reads)", "note": sys.argv[4] if len(sys.argv) > 4 else "",
+    config = json.loads(sys.argv[5]) if len(sys.argv) > 5 else None
+    out = {"config": config, "units": "bytes", "fetch_correction": "FETCH_SIZE x 2 (gfx950, 16-byte-per-lane reads)", "note": sys.argv[4] if len(sys.argv) > 4 else "",
            "kernels": {}}
     for fam in sorted(set(fetch) | set(write)):
         launches = max(n1.get(fam, 0), n2.get(fam, 0))
