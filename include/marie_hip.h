@@ -78,6 +78,8 @@ typedef struct mhip_conv_desc {
   int32_t pool, relu, out_f32;
   int32_t dil;          /* filter dilation, 0/1 = dense */
   int32_t Cin1;         /* with in2_dev: channels [0,Cin1) come from in_dev, [Cin1,Cin) from in2_dev */
+  int32_t ldc;          /* output row pitch in elements, 0 = N (rows must stay 16-byte aligned; unpooled outputs only)        */
+  int32_t pad_cols_writable; /* 1: columns [N, roundup(N, 8)) of a pitched row are the call's own and may be zeroed          */
 } mhip_conv_desc;
 /* in2_dev (may be NULL) is the second tensor of a channel-concatenated input, torch.cat([a, b], dim=1) followed
  * by a 1x1 conv (marie/models/craft/craft.py:63-64,67-69): the concatenation is never materialised.      */

@@ -135,7 +135,7 @@ EXPORTED_SYMBOLS = tuple(s[0] for s in _SIGNATURES)
 class ConvDesc(C.Structure):
     """mirror of ``mhip_conv_desc`` (include/marie_hip.h)"""
     _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "KH", "KW", "pad", "N", "pool", "relu", "out_f32",
-                                         "dil", "Cin1")]
+                                         "dil", "Cin1", "ldc", "pad_cols_writable")]
 
 
 class VitConfig(C.Structure):

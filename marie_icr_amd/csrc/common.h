@@ -103,6 +103,8 @@ struct ConvDesc {
   int pad_x = -1;               // horizontal padding; -1 = same as `pad`
   const void* res = nullptr;    // residual (same shape/type as out: fp32 when out_f32), added before the ReLU; unpooled only
   int ldc = 0;                  // output row pitch in elements; 0 = N
+  int pad_cols_writable = 0;    // 1: with a pitch >= roundup(N, 8) the columns [N, roundup(N, 8)) of every output row belong to this
+                                //    call and may be overwritten (with zeros): lets a ragged N take the 16-byte store path
   int row_period = 0;           // > 0 (unpooled GEMMs): output row = (q / period) * row_stride + row_offset + q % period,
   int row_stride = 0;           //      residual row = q % period (see igemm_common.h)
   int row_offset = 0;

@@ -343,10 +343,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   const float lo2 = (p.relu == ACT_RELU && p.res) ? 0.f : -INFINITY;   // with a residual: after the add
   const bool gelu = p.relu == ACT_GELU;
   // whole, 16-byte aligned column groups in every row — or a row pitch that leaves room for the last, partly filled group
-  // (the logits GEMM: N = 50 265 columns in rows of 50 272): the pad columns receive zeros (weight rows beyond N read the
+  // that the caller has declared its own (pad_cols_writable — the logits GEMM: N = 50 265 columns in rows of 50 272; NOT a GEMM
+  // that writes into a slice of a wider row, whose neighbours would be zeroed): the pad columns receive zeros (weight rows beyond N read the
   // zero page) instead of sending the whole GEMM down the element-wise path (measured 20 us of epilogue per tile there
   // against 4 us)
-  const bool vec = (grow & 15) == 0 && ((p.N & 7) == 0 || (p.ldc >= ((p.N + 7) & ~7)));
+  const bool vec = (grow & 15) == 0 && ((p.N & 7) == 0 || (p.pad_ok && p.ldc >= ((p.N + 7) & ~7))) &&
+                   (((unsigned long long)p.out | (unsigned long long)p.res) & 15) == 0;      // 16-byte stores / residual loads
   float sc4[4], bi4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -607,6 +609,7 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.pad_x = d.pad_x >= 0 ? d.pad_x : d.pad;
   a.res = (const char*)d.res;
   a.ldc = d.ldc;
+  a.pad_ok = d.pad_cols_writable;
   a.row_period = d.row_period; a.row_stride = d.row_stride; a.row_offset = d.row_offset;
   if (d.row_period && (d.pool != POOL_NONE || d.row_period < 1 || d.row_stride < d.row_period))
     return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: periodic row mapping needs an unpooled GEMM and stride >= period");

@@ -198,6 +198,7 @@ extern "C" int mhip_conv2d_nhwc(mhip_ctx* ctx, int precision, const mhip_conv_de
   c.N = d->N; c.pool = d->pool; c.relu = d->relu; c.out_f32 = d->out_f32;
   c.dil = d->dil > 0 ? d->dil : 1;
   c.in2 = in2; c.Cin1 = d->Cin1;
+  c.ldc = d->ldc; c.pad_cols_writable = d->pad_cols_writable;
   return mhip_launch_conv_igemm(ctx, precision, c);
 }
 

@@ -59,7 +59,7 @@ int conv(mhip_ctx* ctx, int prec, const void* in, const void* w, const float* bi
   ConvDesc c;
   c.in = in; c.w = w; c.bias = bias; c.out = out;
   c.B = B; c.H = H; c.W = W; c.Cin = Cin; c.KH = c.KW = k; c.pad = k / 2; c.N = N;
-  c.relu = relu; c.out_f32 = out_f32; c.ldc = ldc;
+  c.relu = relu; c.out_f32 = out_f32; c.ldc = ldc; c.pad_cols_writable = ldc ? 1 : 0;     // pitched outputs here are private [rows][16] / [rows][8] buffers
   return mhip_launch_conv_igemm(ctx, prec, c);
 }
 
@@ -360,7 +360,7 @@ static int dit_run(mhip_dit* m, const uint8_t* const* pages_dev, int B, int h, i
   const long long R = (long long)B * MAX_ROIS;
   if ((rc = mhip_gemm(ctx, prec, pooled, a.d("fc1_w"), R, FC_DIM, K1, nullptr, a.d<float>("fc1_b"), f1, ACT_RELU, 0))) return rc;
   if ((rc = mhip_gemm(ctx, prec, f1, a.d("fc2_w"), R, FC_DIM, FC_DIM, nullptr, a.d<float>("fc2_b"), f2, ACT_RELU, 0))) return rc;
-  if ((rc = mhip_gemm(ctx, prec, f2, a.d("pred_w"), R, 6, FC_DIM, nullptr, a.d<float>("pred_b"), hd, ACT_NONE, 1, nullptr, 8))) return rc;
+  if ((rc = mhip_gemm(ctx, prec, f2, a.d("pred_w"), R, 6, FC_DIM, nullptr, a.d<float>("pred_b"), hd, ACT_NONE, 1, nullptr, 8, 1))) return rc;
   DetFinalDesc fd;
   fd.head = hd; fd.rois = rd.out_boxes; fd.counts = rd.out_counts; fd.images = B; fd.max_rois = MAX_ROIS;
   fd.img_h = g.nh; fd.img_w = g.nw; fd.out_h = h; fd.out_w = w;

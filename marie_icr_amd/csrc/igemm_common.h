@@ -34,6 +34,7 @@ struct IgemmArgs {
   int pad_x;           // horizontal padding (vertical padding is `pad`)
   const char* res;     // optional residual tensor, same shape/type as the output, added before the ReLU
   int ldc;             // output row pitch in elements (>= N): lets a GEMM write into a slice of a wider tensor
+  int pad_ok;          // the pad columns [N, roundup(N, 8)) of a pitched row may be overwritten (ConvDesc::pad_cols_writable)
   int row_period;      // > 0: GEMM row q lands in output row (q / period) * row_stride + row_offset + q % period and takes
   int row_stride;      //      residual row q % period — batched patch embedding: one GEMM over all images writes each
   int row_offset;      //      image's token block (after its cls row) and adds the shared position table

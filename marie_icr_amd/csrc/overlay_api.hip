@@ -76,7 +76,7 @@ int conv(mhip_overlay* m, const void* in, const std::string& name, void* out, in
          int ldc = 0) {
   ConvDesc c;
   c.in = in; c.w = m->arena.d(name + "_w"); c.bias = m->arena.d<float>(name + "_b"); c.out = out;
-  c.B = 1; c.H = H; c.W = W; c.Cin = Cin; c.KH = c.KW = k; c.pad = pad; c.N = N; c.sy = sy; c.ldc = ldc;
+  c.B = 1; c.H = H; c.W = W; c.Cin = Cin; c.KH = c.KW = k; c.pad = pad; c.N = N; c.sy = sy; c.ldc = ldc; c.pad_cols_writable = ldc ? 1 : 0;
   return mhip_launch_conv_igemm(m->ctx, m->precision, c);
 }
 

@@ -354,7 +354,7 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
       if ((rc = mhip_gemm(ctx, prec, hid, a.d(lay(l, "fc2_w")), M, D, F, nullptr, a.d<float>(lay(l, "fc2_b")), x, ACT_NONE, 1, x))) return rc;
       if ((rc = mhip_launch_layernorm2(ctx, prec, x, a.d<float>(lay(l, "fin_ln") + "_g"), a.d<float>(lay(l, "fin_ln") + "_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
     }
-    if ((rc = mhip_gemm(ctx, prec, xt, a.d("out_w"), M, c.vocab, D, nullptr, nullptr, logits, ACT_NONE, 0, nullptr, ldv))) return rc;
+    if ((rc = mhip_gemm(ctx, prec, xt, a.d("out_w"), M, c.vocab, D, nullptr, nullptr, logits, ACT_NONE, 0, nullptr, ldv, 1))) return rc;
     if (step == 0 && step0_logits_host) {
       float* stage = ws.take<float>((size_t)c.vocab * 4);
       for (int i = 0; i < n; ++i) {

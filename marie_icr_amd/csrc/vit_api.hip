@@ -12,11 +12,11 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 
 int gemm(mhip_ctx* ctx, int prec, const void* in, const void* w, long long M, int N, int K, const float* scale,
-         const float* bias, void* out, int act, int out_f32, const void* res = nullptr, int ldc = 0) {
+         const float* bias, void* out, int act, int out_f32, const void* res = nullptr, int ldc = 0, int pad_ok = 0) {
   ConvDesc c;
   c.in = in; c.w = w; c.scale = scale; c.bias = bias; c.out = out;
   c.B = 1; c.H = 1; c.W = (int)M; c.Cin = K; c.N = N;
-  c.relu = act; c.out_f32 = out_f32; c.res = res; c.ldc = ldc;
+  c.relu = act; c.out_f32 = out_f32; c.res = res; c.ldc = ldc; c.pad_cols_writable = pad_ok;
   return mhip_launch_conv_igemm(ctx, prec, c);
 }
 
@@ -25,8 +25,8 @@ std::string blk(int i, const char* s) { return "blocks." + std::to_string(i) + "
 }  // namespace
 
 int mhip_gemm(mhip_ctx* ctx, int prec, const void* in, const void* w, long long M, int N, int K, const float* scale,
-              const float* bias, void* out, int act, int out_f32, const void* res, int ldc) {
-  return gemm(ctx, prec, in, w, M, N, K, scale, bias, out, act, out_f32, res, ldc);
+              const float* bias, void* out, int act, int out_f32, const void* res, int ldc, int pad_ok) {
+  return gemm(ctx, prec, in, w, M, N, K, scale, bias, out, act, out_f32, res, ldc, pad_ok);
 }
 
 // ---------------------------------------------------------------------------------------------------- lifecycle

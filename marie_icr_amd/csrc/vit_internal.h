@@ -44,4 +44,4 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
 int vit_fpn(mhip_vit* m, Carver& ws, int B, const VitRun& run, VitFpnOut* out);
 
 int mhip_gemm(mhip_ctx* ctx, int prec, const void* in, const void* w, long long M, int N, int K, const float* scale,
-              const float* bias, void* out, int act, int out_f32, const void* res = nullptr, int ldc = 0);
+              const float* bias, void* out, int act, int out_f32, const void* res = nullptr, int ldc = 0, int pad_cols_writable = 0);

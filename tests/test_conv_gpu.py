@@ -117,3 +117,39 @@ def test_conv_dilated_and_concat_inputs(ctx):
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
+
+
+@pytest.mark.parametrize("prec_name,N,ldc,own", [("f16", 45, 48, 1), ("f16", 45, 96, 0), ("f32", 45, 48, 1), ("f32", 13, 40, 0),
+                                                   ("f16", 50, 56, 1)])
+def test_pitched_ragged_n_gemm(ctx, prec_name, N, ldc, own):
+    """A GEMM whose N is not a multiple of 8 written into rows of pitch ldc.  With pad_cols_writable (the logits GEMM: N = 50 265
+    in rows of 50 272) the 16-byte store path is taken and the pad columns [N, roundup(N, 8)) come out as zeros; WITHOUT it (a
+    GEMM writing a slice of a wider row) the neighbouring columns must be left untouched."""
+    import torch
+
+    from marie_icr_amd._lib import PREC_F16, PREC_F32, ConvDesc
+
+    prec = PREC_F16 if prec_name == "f16" else PREC_F32
+    dt = torch.float16 if prec_name == "f16" else torch.float32
+    M, K = 300, 128
+    g = torch.Generator().manual_seed(N * 7 + ldc)
+    a = (torch.rand((M, K), generator=g) - 0.5).to(dt)
+    w = (torch.rand((N, K), generator=g) - 0.5).to(dt)
+    bias = torch.rand((N,), generator=g) - 0.5
+    da, dw, db = a.cuda(), w.cuda(), bias.cuda()
+    out = torch.full((M, ldc), 7.0, dtype=dt, device="cuda")
+    d = ConvDesc(M, 1, 1, K, 1, 1, 0, N, 0, 0, 0, 1, 0, ldc, own)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.conv2d_nhwc(prec, d, da.data_ptr(), dw.data_ptr(), 0, db.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    ref = a.double() @ w.double().T + bias.double()
+    got = out.cpu().double()
+    tol = 2e-2 if prec_name == "f16" else 1e-4
+    assert (got[:, :N] - ref).abs().max() <= tol
+    n8 = (N + 7) // 8 * 8
+    if own:
+        assert (got[:, N:n8] == 0).all()                       # the call's own pad columns: zeros
+        assert (got[:, n8:] == 7.0).all()                      # beyond them: untouched
+    else:
+        assert (got[:, N:] == 7.0).all()                       # a slice of a wider row: nothing outside [0, N) is written
+    ctx.set_stream(None)
