@@ -459,7 +459,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
         }
 #pragma unroll
         for (int t = 0; t < NRES16; ++t)
-          if (ook[t]) *(__attribute__((address_space(1))) half8*)dst16[t] = ov[t];   // global, not flat: the asm hides the provenance
+          // global, not flat: the asm hides the provenance.  Non-temporal: the output is read next by another kernel, long after
+          // it has left the L2, and kept out of it the weights stay (+3 % on the ViT GEMMs, tools/ubench/gemm_bench.hip)
+          // The few-row tile's outputs (decoder steps) are small and read back at once: those stay in the L2.
+          if (ook[t]) {
+            if (C::SMALL) *(__attribute__((address_space(1))) half8*)dst16[t] = ov[t];
+            else __builtin_nontemporal_store(ov[t], (__attribute__((address_space(1))) half8*)dst16[t]);
+          }
       } else {
         float4v ov32[NRES32];
         size_t ooff32[NRES32];
@@ -508,7 +514,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
           }
 #pragma unroll
           for (int t = 0; t < NRES32; ++t)
-            if (ook32[t]) *(__attribute__((address_space(1))) float4v*)dst32[t] = ov32[t];
+            if (ook32[t]) {
+              if (C::SMALL) *(__attribute__((address_space(1))) float4v*)dst32[t] = ov32[t];
+              else __builtin_nontemporal_store(ov32[t], (__attribute__((address_space(1))) float4v*)dst32[t]);
+            }
         }
       }
     }
