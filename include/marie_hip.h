@@ -334,6 +334,14 @@ int mhip_overlay_blend(mhip_ctx* ctx, const uint8_t* real_bgr_dev, const uint8_t
 /* replaces: blackout_bboxes, marie/boxes/dit/ulim_dit_box_processor.py:161-198, in place on a device page (BGR).        */
 int mhip_blackout_bboxes(mhip_ctx* ctx, uint8_t* page_dev, int h, int w, const int32_t* boxes_xyxy_host, int n,
                          int* changed);
+/* replaces: the OpenCV chain of crop_to_content (marie/utils/image_utils.py:190-252, behind OcrEngine.extract(crop_to_content=True),
+ * marie/ocr/ocr_engine.py:169-176) and of crop_to_content_box (marie/boxes/dit/ulim_dit_box_processor.py:291-352, behind
+ * psm_sparse(bbox_optimization=True), :608-626): BGR2GRAY, then content_aware ? close_2x3(otsu(divide(gray, blur5x5(gray), 255)))
+ * : otsu(gray).  For each of n rectangles (x, y, w, h, inside the h x w BGR device page) ext[i] = {xmin, ymin, xmax, ymax, count}
+ * of the pixels that come out 0, in rectangle coordinates (count == 0: no such pixel, the rest is 0).  The callers' padding
+ * rules stay on the host (marie_icr_amd/content.py).                                                                           */
+int mhip_content_extents(mhip_ctx* ctx, const uint8_t* page_dev, int h, int w, const int32_t* rects_xywh_host, int n,
+                         int content_aware, int32_t* ext_host);
 
 /* ---- TrOCR recognizer (image encoder + text decoder + beam search) ------------------------------------------------------ */
 /* replaces: TrOcrProcessor's model path, marie/document/trocr_ocr_processor.py:116-180 (preprocess_image, get_text), with

@@ -84,6 +84,7 @@ _SIGNATURES = (
     ("mhip_roi_align_host", _i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     ("mhip_det_final_host", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, _i, _vp, _vp, _vp]),
     ("mhip_blackout_bboxes", _i, [_vp, _vp, _i, _i, _vp, _i, C.POINTER(_i)]),
+    ("mhip_content_extents", _i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     ("mhip_overlay_create", _i, [_vp, _i, _i, C.POINTER(_vp)]),
     ("mhip_overlay_destroy", _i, [_vp]),
     ("mhip_overlay_set_tensor", _i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),

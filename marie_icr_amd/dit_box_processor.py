@@ -6,8 +6,8 @@ Mirrors marie/boxes/dit/ulim_dit_box_processor.py:358-832: same constructor argu
 (line, x) lexsort that leaves ``rect_line_numbers`` unpermuted — quirk Q1 in SURVEY.md section 8).  The detector, the
 blackout and the box/line geometry run in libmarie_hip.so; this file is the control flow between them.
 
-Not carried over: ``bbox_optimization`` (``crop_to_content_box``: OpenCV Otsu / GaussianBlur / morphology — off by default
-in the reference and in every caller on the hot path) raises NotImplementedError.
+``bbox_optimization`` (``crop_to_content_box``, off by default in the reference) shrinks every box to the ink of its snippet
+through csrc/content_ops.hip (marie_icr_amd/content.py).
 """
 from __future__ import annotations
 
@@ -19,6 +19,7 @@ import numpy as np
 
 from ._lib import PREC_F16, PREC_F32, Context, MarieHipError, check
 from .box_processor import PSMode
+from .content import optimize_boxes
 from .dit import DitModel
 from .geometry import find_line_numbers, lines_from_bboxes, merge_boxes
 
@@ -182,8 +183,6 @@ class BoxProcessorUlimDit:
         the page when the blackout changed nothing or nothing was found, else drops boxes overlapping (IoU > 0.1) earlier
         ones.  Returns per page ``(bboxes, classes, scores, lines, classes, device page or None)`` — the last item is the
         pristine page in HBM when the page was not framed (fragments can then be read where they are)."""
-        if bbox_optimization:
-            raise NotImplementedError("bbox_optimization (crop_to_content_box) is not part of this build")
         refinement = self.refinement if bbox_refinement is None else bbox_refinement
         steps = 3 if refinement else 1
         pages = []
@@ -197,7 +196,7 @@ class BoxProcessorUlimDit:
             dev = self._upload(framed)
             # the refinement image: boxes found so far are painted white on it; the pristine copy stays for the fragments
             work = dev.clone() if steps > 1 else dev
-            pages.append({"image": framed, "adj": (adj_x, adj_y), "dev": dev if framed is image else None, "work": work,
+            pages.append({"image": framed, "adj": (adj_x, adj_y), "dev": dev if framed is image else None, "pristine": dev, "work": work,
                           "bboxes": [], "classes": [], "scores": [], "active": True})
         for i in range(steps):
             groups: Dict[Tuple[int, ...], list] = {}
@@ -227,6 +226,10 @@ class BoxProcessorUlimDit:
                     pg["scores"].extend(np.delete(scores_, tgt, axis=0))
         out = []
         for pg in pages:
+            if bbox_optimization and len(pg["bboxes"]):
+                # ulim_dit_box_processor.py:608-626: every box shrinks to the ink of its snippet (all boxes of the page in one call)
+                ph, pw = pg["image"].shape[:2]
+                pg["bboxes"] = optimize_boxes(self.ctx, pg["pristine"].data_ptr(), ph, pw, pg["bboxes"], bool(bbox_context_aware))
             bb, cc, sc = [], [], []
             for box, cls, score in zip(pg["bboxes"], pg["classes"], pg["scores"]):   # names swapped as in the reference (Q4)
                 h = box[2] - box[0]

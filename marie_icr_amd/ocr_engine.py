@@ -8,7 +8,8 @@ full-page and region extraction.
 Output-invariant work of the reference that is NOT repeated per page (SURVEY.md §3.1 hot-loop notes): the deep copy of
 every frame (ocr_engine.py:118), the md5 of all pixels used only as a debug-directory key (:119), and the white-canvas
 copy when the padding is 0 (:181-184).  ``crop_to_content`` (an OpenCV blur/Otsu/morphology chain,
-marie/utils/image_utils.py:190-252) is not provided on this path and raises if requested.
+marie/utils/image_utils.py:190-252) runs in csrc/content_ops.hip (marie_icr_amd/content.py); the page then sits on a white canvas
+with 4 px of padding as in :169-184.
 """
 from __future__ import annotations
 
@@ -117,7 +118,20 @@ class OcrEngine:
                                   icr_processor, **kwargs):
         """reference: ocr_engine.py:154-221."""
         if kwargs.get("crop_to_content", False):
-            raise NotImplementedError("crop_to_content is not available on the MI355X path")
+            # ocr_engine.py:169-184: the page is cropped to its content and set on a white canvas with 4 px of padding
+            from .content import crop_to_content
+
+            ctx = getattr(box_processor, "ctx", None) or getattr(icr_processor, "ctx", None)
+            if ctx is None:
+                raise RuntimeError("crop_to_content needs a processor with a device context (ctx)")
+            padded = []
+            for img in frames:
+                img = crop_to_content(ctx, img)
+                h, w = img.shape[:2]
+                canvas = np.full((h + 8, w + 8, 3), 255, np.uint8)
+                canvas[4:h + 4, 4:w + 4] = img if img.ndim == 3 else img[:, :, None]
+                padded.append(canvas)
+            frames = padded
         if hasattr(box_processor, "extract_bounding_boxes_batch") and hasattr(icr_processor, "recognize_pages"):
             return self._fullpage_batched(frames, queue_id, checksum, pms_mode, coordinate_format, box_processor,
                                           icr_processor)

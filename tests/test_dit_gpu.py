@@ -343,3 +343,33 @@ def test_box_processor_small_image_is_framed(ctx, small_case):
     np.testing.assert_array_equal(f3, r3)
     rects, frags, *_ = bp.extract_bounding_boxes("t", "k", tall, PSMode.SPARSE)      # the whole path accepts such a page
     assert len(rects) == len(frags)
+
+
+def test_bbox_optimization_switch(ctx, small_case, monkeypatch):
+    """psm_sparse(bbox_optimization=True) (ulim_dit_box_processor.py:608-626): same output with the HIP measurement of the
+    snippets as with the reference's per-box loop over the CPU restatement of crop_to_content_box."""
+    import marie_icr_amd.dit_box_processor as dbp
+    from oracle import content_ref
+
+    st, page, *_ = small_case
+    bp = dbp.BoxProcessorUlimDit(cuda=True, state=st, model="base", precision="f32", ctx=ctx, config=_config(ctx), refinement=False)
+    for aware in (True, False):
+        got = bp.psm_sparse(page, bbox_optimization=True, bbox_context_aware=aware)
+
+        def by_the_book(ctx_, ptr, ph, pw, bboxes, content_aware):
+            out = []
+            for box in bboxes:
+                b = np.array(box).astype(np.int32)
+                x0, y0, x1, y1 = b
+                off, _ = content_ref.crop_to_content_box(page[y0:y0 + (y1 - y0), x0:x0 + (x1 - x0)], content_aware)
+                out.append([b[0] + off[0], b[1] + off[1], b[2] - (off[2] - off[0]), b[3] - (off[3] - off[1])])
+            return out
+
+        monkeypatch.setattr(dbp, "optimize_boxes", by_the_book)
+        want = bp.psm_sparse(page, bbox_optimization=True, bbox_context_aware=aware)
+        monkeypatch.undo()
+        assert len(got[0]) > 5
+        np.testing.assert_array_equal(np.asarray(got[0]), np.asarray(want[0]))
+        np.testing.assert_array_equal(np.asarray(got[3]), np.asarray(want[3]))
+    plain = bp.psm_sparse(page)
+    assert not np.array_equal(np.asarray(plain[0]), np.asarray(got[0]))      # the switch does something

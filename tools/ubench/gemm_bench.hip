@@ -57,8 +57,9 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&A, amax * 2 + 4096)); CK(hipMalloc((void**)&C, cmax * 2)); CK(hipMalloc((void**)&R, (size_t)rows * 768 * 2));
   CK(hipMalloc((void**)&W, (size_t)3072 * 3072 * 2)); CK(hipMalloc((void**)&bias, 3072 * 4));
   CK(hipMemset(bias, 0, 3072 * 4));
-  fill_kernel<<<1024, 256, 0, ctx.stream>>>(A, amax, 1u, 1.0f);
-  fill_kernel<<<1024, 256, 0, ctx.stream>>>(W, (size_t)3072 * 3072, 2u, 0.05f);
+  const float amp = getenv("GB_ZERO") ? 0.f : 1.f;      // GB_ZERO=1: zero operands (what the clock does under load, not a result)
+  fill_kernel<<<1024, 256, 0, ctx.stream>>>(A, amax, 1u, 1.0f * amp);
+  fill_kernel<<<1024, 256, 0, ctx.stream>>>(W, (size_t)3072 * 3072, 2u, 0.05f * amp);
   fill_kernel<<<1024, 256, 0, ctx.stream>>>(R, (size_t)rows * 768, 3u, 1.0f);
   double* dsum;
   CK(hipMalloc((void**)&dsum, 8));
