@@ -671,6 +671,14 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   const int bm = (bn == 64) ? 512 : 256;
   a.mtiles = (a.M + bm - 1) / bm;
   a.ntiles = (a.N + bn - 1) / bn;
+  // too few 256 x 256 tiles to occupy the 256 CUs but enough 256 x 128 ones for one round (decoder-step GEMMs into 1024
+  // columns: 7680 x 1024 = 120 / 240 tiles): the wider-than-tall tile stages 25 % fewer bytes per MFMA than 128 x 128
+  static const bool mid_off = getenv("MARIE_HIP_NO_MID_TILE") != nullptr;      // A/B aid
+  if (!mid_off && bn == 256 && a.mtiles * a.ntiles < 192 && a.mtiles * ((a.N + 127) / 128) >= 192 && !force_bn) {
+    a.ntiles = (a.N + 127) / 128;
+    ctx->prof[MHIP_K_IGEMM_T128].flops += fl;
+    return precision == MHIP_PREC_F16 ? launch_t<_Float16, 128>(ctx, a, d.pool) : launch_t<float, 128>(ctx, a, d.pool);
+  }
   // too few big tiles to occupy the 256 CUs (decoder-step GEMMs, heads on small maps): 128 x 128 tiles instead
   if (a.mtiles * a.ntiles < 192 && a.N > 64 && d.pool == POOL_NONE && !d.in2) {
     a.mtiles = (a.M + 127) / 128;
