@@ -745,21 +745,40 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
     out = {}
     for name, fixed, refine, n_pages in (("fixed_lines", True, False, P), ("detector_driven", False, False, min(P, 8)),
                                          ("detector_driven_refinement", False, True, min(P, 8))):
-        eng = MarieHipOcrEngine(box_processor=make_box(fixed, refine), default_ocr_processor=tp)
-        eng.page_batch = min(P, 32)       # two batches at 64 pages: the detector of the second runs under the recognizer of the first
+        bp = make_box(fixed, refine)
+        eng = MarieHipOcrEngine(box_processor=bp, default_ocr_processor=tp)
+        eng.page_batch = min(P, args.engine_page_batch)    # several batches: the detector of batch k + 1 runs under the recognizer of batch k
+        # wall time spent inside the two processors (they run on two host threads, so the two can add up to more than the call)
+        spent = {"detect_s": 0.0, "recognize_s": 0.0}
+
+        def timed(fn, key):
+            def wrapper(*a, **k):
+                t = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    spent[key] += time.perf_counter() - t
+            return wrapper
+        bp.extract_bounding_boxes_batch = timed(bp.extract_bounding_boxes_batch, "detect_s")
+        orig_rec = tp.recognize_pages
+        tp.recognize_pages = timed(orig_rec, "recognize_s")
         fr = frames[:n_pages]
         reps = 2 if fixed else 1
         if fixed:
             eng.extract(fr, PSMode.SPARSE, CoordinateFormat.XYXY)     # warm-up
         torch.cuda.synchronize()
+        spent.update(detect_s=0.0, recognize_s=0.0)
         t0 = time.perf_counter()
         for _ in range(reps):
             res = eng.extract(fr, PSMode.SPARSE, CoordinateFormat.XYXY)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        tp.recognize_pages = orig_rec
         words = sum(len(r["words"]) for r in res) / len(res)
         out[name] = {"value": reps * n_pages / dt, "unit": "pages/s", "pages_per_call": n_pages, "words_per_page": words,
-                     "lines_per_page": sum(len(r["lines"]) for r in res) / len(res)}
+                     "lines_per_page": sum(len(r["lines"]) for r in res) / len(res), "page_batch": eng.page_batch,
+                     "s_per_call": dt / reps, "s_in_box_processor": spent["detect_s"] / reps,
+                     "s_in_ocr_processor": spent["recognize_s"] / reps}
     out["what"] = ("MarieHipOcrEngine.extract(frames) end to end, host numpy frames in (H2D inside), result dictionaries out; "
                    "fixed_lines: the detector runs in full but the generator's 40 line boxes go on (the headline's fixed work, "
                    "bbox_refinement=False); detector_driven: whatever the random-weight detector emits becomes a crop "
@@ -786,6 +805,7 @@ def launch_ranks(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--engine-page-batch", type=int, default=32, help="pages per detector / recognizer batch of the engine_api leg")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["dit_trocr", "craft_crnn", "pages", "crnn"], default="dit_trocr")

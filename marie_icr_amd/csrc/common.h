@@ -59,6 +59,9 @@ struct mhip_ctx {
 };
 
 int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...);
+// Teardown: wait for the device, not for ctx->stream — the caller's stream (a torch stream handed in by mhip_set_stream) may
+// already be gone when an object is destroyed late (interpreter shutdown), and synchronising a dead handle aborts the process
+inline void mhip_quiesce() { (void)hipDeviceSynchronize(); }
 int mhip_ensure_workspace(mhip_ctx* ctx, size_t bytes);
 void mhip_prof_begin(mhip_ctx* ctx, int kid, hipEvent_t* e0);
 void mhip_prof_end(mhip_ctx* ctx, int kid, hipEvent_t e0);

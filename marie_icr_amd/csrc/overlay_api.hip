@@ -103,7 +103,7 @@ extern "C" int mhip_overlay_create(mhip_ctx* ctx, int precision, int ngf, mhip_o
 
 extern "C" int mhip_overlay_destroy(mhip_overlay* m) {
   if (!m) return MHIP_OK;
-  (void)hipStreamSynchronize(m->ctx->stream);
+  mhip_quiesce();
   m->arena.release();
   delete m;
   return MHIP_OK;

@@ -97,7 +97,7 @@ extern "C" int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_
 
 extern "C" int mhip_trocr_destroy(mhip_trocr* m) {
   if (!m) return MHIP_OK;
-  (void)hipStreamSynchronize(m->ctx->stream);
+  mhip_quiesce();
   mhip_vit_destroy(m->vit);
   m->arena.release();
   if (m->frag_crops) (void)hipFree(m->frag_crops);

@@ -72,7 +72,7 @@ extern "C" int mhip_vit_create(mhip_ctx* ctx, int precision, const mhip_vit_conf
 
 extern "C" int mhip_vit_destroy(mhip_vit* m) {
   if (!m) return MHIP_OK;
-  (void)hipStreamSynchronize(m->ctx->stream);
+  mhip_quiesce();
   m->arena.release();
   for (auto& t : m->pos_tables) (void)hipFree(t.dev);
   delete m;

@@ -196,6 +196,13 @@ class OcrEngine:
                         q.put((idx, detect(idx)))
             except BaseException as e:              # surfaced on the consumer side
                 q.put(e)
+            finally:
+                # det_stream dies with this call: the detector's context must not keep its handle (a later call sets its own
+                # stream again; a destroy that synchronised the dead handle would abort the process)
+                ctx = getattr(box_processor, "ctx", None)
+                if ctx is not None:
+                    det_stream.synchronize()
+                    ctx.set_stream(None)
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()

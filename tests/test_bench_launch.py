@@ -65,3 +65,23 @@ def test_two_rank_rehearsal_matches_one_rank():
     one48 = _json_line(_run(["--gpus", "1"] + [a if a != "24" else "48" for a in common]).stdout)
     assert two["mixed_dpi"]["pages"] == one48["mixed_dpi"]["pages"] == 48
     assert two["mixed_dpi"]["result_checksum"] == one48["mixed_dpi"]["result_checksum"]
+
+
+@pytest.mark.gpu
+def test_all_legs_run_and_the_process_exits_cleanly():
+    """The default command's shape at a reduced size with every secondary leg on (engine_api, overlay, det_passes_3, mixed DPI,
+    cpu parity sample off): one JSON line with the contract's fields, exit code 0.  Regression: the engine leg's detector thread
+    used to leave its (dead) torch stream in the detector's context, and the teardown's hipStreamSynchronize on it aborted the
+    interpreter AFTER the line was printed (exit 134)."""
+    r = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--pages", "8", "--det-batch", "4", "--decode-len", "3", "--mixed-pages", "6",
+              "--no-cpu-baseline", "--host-steps", "0", "--engine-page-batch", "4"])
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    line = _json_line(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    eng = line["engine_api"]
+    assert eng["fixed_lines"]["value"] > 0 and eng["fixed_lines"]["page_batch"] == 4
+    assert eng["fixed_lines"]["lines_per_page"] == 40
+    assert line["overlay"]["value"] > 0
