@@ -189,8 +189,9 @@ int mhip_launch_argmax_rows(mhip_ctx* ctx, const float* logits, int ld, int C, i
 int mhip_launch_rowmax_softmax(mhip_ctx* ctx, const float* logits, int rows, int C, int* idx, float* pmax);
 
 // ------------------------------------------------------------------ ViT encoder ops (vit_ops.hip)
-int mhip_launch_layernorm(mhip_ctx* ctx, int precision, const float* x, const float* g, const float* b, void* out,
-                          int rows, int D, float eps);
+// x: the residual stream, fp32 — or f16 (x_f16, f16 mode only)
+int mhip_launch_layernorm(mhip_ctx* ctx, int precision, const void* x, const float* g, const float* b, void* out,
+                          int rows, int D, float eps, int x_f16 = 0);
 // softmax(Q K^T) V for `images` x `heads` independent (head_dim 64) problems; q is pre-scaled by head_dim^-0.5 * log2(e).
 struct AttnDesc {
   const void* q = nullptr;    // [images*npad_q][ldq] T, head h at column h*64
@@ -207,10 +208,11 @@ int mhip_launch_attention(mhip_ctx* ctx, int precision, const AttnDesc& d);
 double mhip_attention_flops(const AttnDesc& d);
 int mhip_launch_patchify(mhip_ctx* ctx, int precision, const uint8_t* imgs, int B, int th, int tw, int hp, int wp, int P,
                          int swap_rb, float mean, float stdv, void* out, int ld);
-int mhip_launch_token_init(mhip_ctx* ctx, float* x, const float* cls_row, int B, int npad, int n_tok, int D);
-int mhip_launch_tokens_to_map(mhip_ctx* ctx, int precision, const float* x, void* out, int B, int npad, int np, int D);
+int mhip_launch_token_init(mhip_ctx* ctx, void* x, const float* cls_row, int B, int npad, int n_tok, int D, int x_f16 = 0);
+int mhip_launch_tokens_to_map(mhip_ctx* ctx, int precision, const void* x, void* out, int B, int npad, int np, int D, int x_f16 = 0);
 int mhip_launch_posemb_bicubic(mhip_ctx* ctx, const float* tab, int gh, int gw, float* out, int hp, int wp, int D);
 int mhip_launch_convert_rows(mhip_ctx* ctx, int precision, const void* in, float* out, int rows, int D);
+int mhip_launch_narrow_f16(mhip_ctx* ctx, const float* in, void* out, long long n);
 int mhip_launch_unnest(mhip_ctx* ctx, int precision, const void* in, const void* coarse, void* out, int out_f32, int B,
                        int H, int W, int C, int nest);
 

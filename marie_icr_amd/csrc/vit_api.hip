@@ -5,6 +5,8 @@
 // forward_features (marie/models/unilm/trocr/deit.py:105-146).  One object = one weight arena + the launch sequence.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "vit_internal.h"
 
 namespace {
@@ -44,6 +46,7 @@ extern "C" int mhip_vit_create(mhip_ctx* ctx, int precision, const mhip_vit_conf
   m->ctx = ctx;
   m->precision = precision;
   m->cfg = *cfg;
+  m->x16 = precision == MHIP_PREC_F16 && getenv("MARIE_HIP_RESIDUAL_F16") != nullptr;
   const size_t es = m->esz(), D = cfg->dim, K0 = 3 * 16 * 16;
   Arena& a = m->arena;
   a.take("pe_w", D * K0 * es);
@@ -74,7 +77,7 @@ extern "C" int mhip_vit_destroy(mhip_vit* m) {
   if (!m) return MHIP_OK;
   mhip_quiesce();
   m->arena.release();
-  for (auto& t : m->pos_tables) (void)hipFree(t.dev);
+  for (auto& t : m->pos_tables) { (void)hipFree(t.dev); if (t.dev16) (void)hipFree(t.dev16); }
   delete m;
   return MHIP_OK;
 }
@@ -235,7 +238,7 @@ extern "C" int mhip_vit_finalize(mhip_vit* m) {
   if (rc) return rc;
   m->ready = true;
   m->store.t.clear();
-  for (auto& t : m->pos_tables) (void)hipFree(t.dev);
+  for (auto& t : m->pos_tables) { (void)hipFree(t.dev); if (t.dev16) (void)hipFree(t.dev16); }
   m->pos_tables.clear();
   return MHIP_OK;
 }
@@ -277,17 +280,23 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
   run->g = g;
   const Arena& a = m->arena;
   float* pos_dev = nullptr;
+  const bool x16 = m->x16 && prec == MHIP_PREC_F16;
+  void* pos16 = nullptr;
   for (const auto& t : m->pos_tables)
-    if (t.hp == g.hp && t.wp == g.wp) pos_dev = t.dev;
+    if (t.hp == g.hp && t.wp == g.wp) { pos_dev = t.dev; pos16 = t.dev16; }
   if (!pos_dev) {   // first page of this geometry: resize the position table once and keep it
     if (m->pos_tables.size() >= 64) return mhip_fail(ctx, MHIP_ENOMEM, "vit: more than 64 distinct page geometries");
     MHIP_HIP(ctx, hipMalloc((void**)&pos_dev, (size_t)g.np * D * 4));
-    m->pos_tables.push_back({g.hp, g.wp, pos_dev});
     int rc = mhip_launch_posemb_bicubic(ctx, a.d<float>("pos"), c.pos_h, c.pos_w, pos_dev, g.hp, g.wp, D);
     if (rc) return rc;
+    if (x16) {
+      MHIP_HIP(ctx, hipMalloc(&pos16, (size_t)g.np * D * 2));
+      if ((rc = mhip_launch_narrow_f16(ctx, pos_dev, pos16, (long long)g.np * D))) return rc;
+    }
+    m->pos_tables.push_back({g.hp, g.wp, pos_dev, pos16});
   }
   const size_t R = (size_t)B * g.npad;
-  float* x = ws.take<float>(R * D * 4);
+  void* x = ws.take<float>(R * D * 4);      // fp32 stream, or f16 in the first half of it
   char* ln = ws.take(R * D * es);
   char* qk = ws.take((R + 128) * 2 * D * es);
   char* vt = ws.take((D * R + 128) * es);
@@ -303,16 +312,16 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
   {   // all images at once: row q of the patch matrix -> token row (q / np) * npad + 1 + q % np, + position row q % np
     if ((rc = mhip_launch_patchify(ctx, prec, imgs, B, th, tw, g.hp, g.wp, P, swap_rb, 127.5f, 127.5f, hid, K0))) return rc;
     ConvDesc cd;
-    cd.in = hid; cd.w = a.d("pe_w"); cd.bias = a.d<float>("pe_b"); cd.out = x; cd.res = pos_dev;
-    cd.B = 1; cd.H = 1; cd.W = B * g.np; cd.Cin = K0; cd.N = D; cd.out_f32 = 1;
+    cd.in = hid; cd.w = a.d("pe_w"); cd.bias = a.d<float>("pe_b"); cd.out = x; cd.res = x16 ? pos16 : (void*)pos_dev;
+    cd.B = 1; cd.H = 1; cd.W = B * g.np; cd.Cin = K0; cd.N = D; cd.out_f32 = x16 ? 0 : 1;
     cd.row_period = g.np; cd.row_stride = g.npad; cd.row_offset = 1;
     if ((rc = mhip_launch_conv_igemm(ctx, prec, cd))) return rc;
   }
-  if ((rc = mhip_launch_token_init(ctx, x, a.d<float>("cls"), B, g.npad, g.n_tok, D))) return rc;
+  if ((rc = mhip_launch_token_init(ctx, x, a.d<float>("cls"), B, g.npad, g.n_tok, D, x16))) return rc;
   int tap_at = 0;
   if (c.fpn) for (int j = 0; j < 4; ++j) run->tap[j] = ws.take((size_t)B * g.np * D * es);
   for (int i = 0; i < c.depth; ++i) {
-    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>(blk(i, "ln1_g")), a.d<float>(blk(i, "ln1_b")), ln, (int)R, D, c.ln_eps))) return rc;
+    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>(blk(i, "ln1_g")), a.d<float>(blk(i, "ln1_b")), ln, (int)R, D, c.ln_eps, x16))) return rc;
     if ((rc = gemm(ctx, prec, ln, a.d(blk(i, "qk_w")), (long long)R, 2 * D, D, nullptr, a.d<float>(blk(i, "qk_b")), qk, ACT_NONE, 0))) return rc;
     if ((rc = gemm(ctx, prec, a.d(blk(i, "v_w")), ln, D, (int)R, D, nullptr, nullptr, vt, ACT_NONE, 0))) return rc;   // V^T = W_v X^T
     AttnDesc ad;
@@ -320,14 +329,14 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
     ad.ldq = ad.ldk = 2 * D; ad.ldv = (int)R; ad.ldo = D;
     ad.images = B; ad.heads = c.heads; ad.npad_q = ad.npad_k = g.npad; ad.n_queries = ad.n_keys = g.n_tok;
     if ((rc = mhip_launch_attention(ctx, prec, ad))) return rc;
-    if ((rc = gemm(ctx, prec, ao, a.d(blk(i, "proj_w")), (long long)R, D, D, a.d<float>(blk(i, "proj_s")), a.d<float>(blk(i, "proj_b")), x, ACT_NONE, 1, x))) return rc;
-    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>(blk(i, "ln2_g")), a.d<float>(blk(i, "ln2_b")), ln, (int)R, D, c.ln_eps))) return rc;
+    if ((rc = gemm(ctx, prec, ao, a.d(blk(i, "proj_w")), (long long)R, D, D, a.d<float>(blk(i, "proj_s")), a.d<float>(blk(i, "proj_b")), x, ACT_NONE, x16 ? 0 : 1, x))) return rc;
+    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>(blk(i, "ln2_g")), a.d<float>(blk(i, "ln2_b")), ln, (int)R, D, c.ln_eps, x16))) return rc;
     if ((rc = gemm(ctx, prec, ln, a.d(blk(i, "fc1_w")), (long long)R, 4 * D, D, nullptr, a.d<float>(blk(i, "fc1_b")), hid, ACT_GELU, 0))) return rc;
-    if ((rc = gemm(ctx, prec, hid, a.d(blk(i, "fc2_w")), (long long)R, D, 4 * D, a.d<float>(blk(i, "fc2_s")), a.d<float>(blk(i, "fc2_b")), x, ACT_NONE, 1, x))) return rc;
+    if ((rc = gemm(ctx, prec, hid, a.d(blk(i, "fc2_w")), (long long)R, D, 4 * D, a.d<float>(blk(i, "fc2_s")), a.d<float>(blk(i, "fc2_b")), x, ACT_NONE, x16 ? 0 : 1, x))) return rc;
     if (c.fpn)
       for (int j = 0; j < 4; ++j)
         if (c.taps[j] == i) {
-          if ((rc = mhip_launch_tokens_to_map(ctx, prec, x, run->tap[j], B, g.npad, g.np, D))) return rc;
+          if ((rc = mhip_launch_tokens_to_map(ctx, prec, x, run->tap[j], B, g.npad, g.np, D, x16))) return rc;
           ++tap_at;
         }
   }
@@ -337,7 +346,7 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
     // past the last image
     run->tokens = ws.take((R + 64) * D * es);
     MHIP_HIP(ctx, hipMemsetAsync(run->tokens + R * D * es, 0, (size_t)64 * D * es, ctx->stream));
-    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>("norm_g"), a.d<float>("norm_b"), run->tokens, (int)R, D, c.ln_eps))) return rc;
+    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>("norm_g"), a.d<float>("norm_b"), run->tokens, (int)R, D, c.ln_eps, x16))) return rc;
   }
   (void)tap_at;
   return MHIP_OK;
@@ -407,7 +416,13 @@ extern "C" int mhip_vit_forward_host(mhip_vit* m, const uint8_t* imgs_host, int 
         MHIP_HIP(ctx, hipMemcpyAsync(tokens_out + (size_t)b * g.n_tok * D, stage, (size_t)g.n_tok * D * 4, hipMemcpyDeviceToHost, ctx->stream));
         MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
       } else {
-        MHIP_HIP(ctx, hipMemcpyAsync(tokens_out + (size_t)b * g.n_tok * D, run.x + (size_t)b * g.npad * D, (size_t)g.n_tok * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (m->x16 && m->precision == MHIP_PREC_F16) {      // f16 stream: widen through the staging buffer
+          if ((rc = mhip_launch_convert_rows(ctx, m->precision, (const char*)run.x + (size_t)b * g.npad * D * 2, stage, g.n_tok, (int)D))) return rc;
+          MHIP_HIP(ctx, hipMemcpyAsync(tokens_out + (size_t)b * g.n_tok * D, stage, (size_t)g.n_tok * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+          MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+          MHIP_HIP(ctx, hipMemcpyAsync(tokens_out + (size_t)b * g.n_tok * D, (const float*)run.x + (size_t)b * g.npad * D, (size_t)g.n_tok * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
       }
     }
   }

@@ -10,7 +10,8 @@ struct mhip_vit {
   Arena arena;
   // position tables resized to the patch grids seen so far (mixed-DPI streams alternate between a few page sizes);
   // built once per geometry, never inside a steady-state forward
-  struct PosTable { int hp, wp; float* dev; };
+  struct PosTable { int hp, wp; float* dev; void* dev16; };   // dev16: the same table in f16 (f16 residual stream), or null
+  bool x16 = false;            // f16 mode with an f16 residual stream (as the reference's .half() path): MARIE_HIP_RESIDUAL_F16
   std::vector<PosTable> pos_tables;
   bool ready = false;
   size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
@@ -24,7 +25,7 @@ struct VitGeom {
 
 struct VitRun {
   VitGeom g;
-  float* x = nullptr;         // fp32 residual stream [B*npad][D]
+  void* x = nullptr;          // residual stream [B*npad][D]: fp32, or f16 when the model keeps an f16 stream
   char* tap[4] = {nullptr};   // T [B*np][D] patch tokens after blocks cfg.taps[j]
   char* tokens = nullptr;     // T [B*npad][D] after the final norm (final_norm models)
 };

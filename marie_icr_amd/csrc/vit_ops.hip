@@ -25,20 +25,27 @@ namespace {
 constexpr int HD = 64;            // head dim of every model on this path (768/12, 1024/16)
 
 // ------------------------------------------------------------------------------------------------------- LayerNorm
-// one wave per row; D % 256 == 0, D <= 1024.  Two-pass (mean, then centred variance) in registers, fp32.
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+// one wave per row; D % 256 == 0, D <= 1024.  Two-pass (mean, then centred variance) in registers, fp32.  XT: element type of the
+// residual stream that is normalised (fp32, or f16 when the model keeps an f16 stream as the reference's .half() path does).
+template <typename T, typename XT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, T* __restrict__ out, int rows,
                                                         int D, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const int nv = D >> 8;   // float4 per lane
+  const int nv = D >> 8;   // 4-element groups per lane
   float4v v[4];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     if (i < nv) {
-      v[i] = *(const float4v*)(x + (size_t)row * D + (i * 64 + lane) * 4);
+      if (sizeof(XT) == 4) {
+        v[i] = *(const float4v*)((const float*)x + (size_t)row * D + (i * 64 + lane) * 4);
+      } else {
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const half4 h = *(const half4*)((const _Float16*)x + (size_t)row * D + (i * 64 + lane) * 4);
+        v[i] = (float4v){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      }
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
 #pragma unroll
@@ -337,27 +344,28 @@ __global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict
 }
 
 // x[img][0] = cls + pos[0]; rows n_tok.. npad-1 = 0   (fp32 residual stream)
-__global__ void token_init_kernel(float* x, const float* cls_row, int B, int npad, int n_tok, int D) {
+template <typename XT>
+__global__ void token_init_kernel(XT* x, const float* cls_row, int B, int npad, int n_tok, int D) {
   const int rows_per = 1 + (npad - n_tok);
   const long long total = (long long)B * rows_per * D;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int d = (int)(e % D);
     const int r = (int)((e / D) % rows_per), b = (int)(e / ((long long)D * rows_per));
     const int row = r == 0 ? 0 : n_tok + r - 1;
-    x[((size_t)b * npad + row) * D + d] = r == 0 ? cls_row[d] : 0.f;
+    x[((size_t)b * npad + row) * D + d] = (XT)(r == 0 ? cls_row[d] : 0.f);
   }
 }
 
 // fp32 tokens (without cls) -> T feature map rows [B][n_tok-1][D]
-template <typename T>
-__global__ void tokens_to_map_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int npad, int np, int D) {
+template <typename T, typename XT>
+__global__ void tokens_to_map_kernel(const XT* __restrict__ x, T* __restrict__ out, int B, int npad, int np, int D) {
   const long long total = (long long)B * np * (D / 4);
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(e % (D / 4));
     const long long r = e / (D / 4);
     const int pidx = (int)(r % np), b = (int)(r / np);
-    const float4v v = *(const float4v*)(x + ((size_t)b * npad + 1 + pidx) * D + c4 * 4);
-    T o4[4] = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+    const XT* src = x + ((size_t)b * npad + 1 + pidx) * D + c4 * 4;
+    T o4[4] = {(T)src[0], (T)src[1], (T)src[2], (T)src[3]};
     T* dst = out + ((size_t)b * np + pidx) * D + c4 * 4;
     if (sizeof(T) == 2) *(uint64_t*)dst = *(uint64_t*)o4;
     else *(float4v*)dst = *(float4v*)o4;
@@ -412,6 +420,10 @@ __global__ void convert_rows_kernel(const T* __restrict__ in, float* __restrict_
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) out[e] = (float)in[e];
 }
 
+__global__ void narrow_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long long n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) out[e] = (_Float16)in[e];
+}
+
 // nested 2x2 row order (depth `nest`) -> raster NHWC, optionally adding the 2x nearest-upsampled coarser level
 // (FPN top-down path: F.interpolate(scale_factor=2, mode="nearest") + lateral).  OT = T or float.
 template <typename T, typename OT>
@@ -450,14 +462,17 @@ inline int grid_for(long long total, int block) { return (int)std::min<long long
     if (_e != hipSuccess) return mhip_fail((ctx), MHIP_EHIP, what " launch: %s", hipGetErrorString(_e));    \
   } while (0)
 
-int mhip_launch_layernorm(mhip_ctx* ctx, int precision, const float* x, const float* g, const float* b, void* out,
-                          int rows, int D, float eps) {
+int mhip_launch_layernorm(mhip_ctx* ctx, int precision, const void* x, const float* g, const float* b, void* out,
+                          int rows, int D, float eps, int x_f16) {
   if (D % 256 != 0 || D > 1024 || rows <= 0) return mhip_fail(ctx, MHIP_EINVAL, "layernorm: D=%d rows=%d", D, rows);
+  if (x_f16 && precision != MHIP_PREC_F16) return mhip_fail(ctx, MHIP_EINVAL, "layernorm: an f16 stream needs the f16 mode");
   dim3 grid((rows + 3) / 4), block(256);
-  if (precision == MHIP_PREC_F16)
-    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, block, 0, ctx->stream, x, g, b, (_Float16*)out, rows, D, eps));
+  if (precision == MHIP_PREC_F16 && x_f16)
+    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL((layernorm_kernel<_Float16, _Float16>), grid, block, 0, ctx->stream, (const _Float16*)x, g, b, (_Float16*)out, rows, D, eps));
+  else if (precision == MHIP_PREC_F16)
+    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL((layernorm_kernel<_Float16, float>), grid, block, 0, ctx->stream, (const float*)x, g, b, (_Float16*)out, rows, D, eps));
   else
-    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, ctx->stream, x, g, b, (float*)out, rows, D, eps));
+    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, ctx->stream, (const float*)x, g, b, (float*)out, rows, D, eps));
   CHECK_LAUNCH(ctx, "layernorm");
   return 0;
 }
@@ -509,20 +524,25 @@ int mhip_launch_patchify(mhip_ctx* ctx, int precision, const uint8_t* img, int B
   return 0;
 }
 
-int mhip_launch_token_init(mhip_ctx* ctx, float* x, const float* cls_row, int B, int npad, int n_tok, int D) {
+int mhip_launch_token_init(mhip_ctx* ctx, void* x, const float* cls_row, int B, int npad, int n_tok, int D, int x_f16) {
   const long long total = (long long)B * (1 + npad - n_tok) * D;
-  PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(token_init_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, x, cls_row, B, npad, n_tok, D));
+  if (x_f16)
+    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(token_init_kernel<_Float16>, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, (_Float16*)x, cls_row, B, npad, n_tok, D));
+  else
+    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(token_init_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, (float*)x, cls_row, B, npad, n_tok, D));
   CHECK_LAUNCH(ctx, "token_init");
   return 0;
 }
 
-int mhip_launch_tokens_to_map(mhip_ctx* ctx, int precision, const float* x, void* out, int B, int npad, int np, int D) {
+int mhip_launch_tokens_to_map(mhip_ctx* ctx, int precision, const void* x, void* out, int B, int npad, int np, int D, int x_f16) {
   const long long total = (long long)B * np * (D / 4);
   dim3 grid(grid_for(total, 256)), block(256);
-  if (precision == MHIP_PREC_F16)
-    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(tokens_to_map_kernel<_Float16>, grid, block, 0, ctx->stream, x, (_Float16*)out, B, npad, np, D));
+  if (precision == MHIP_PREC_F16 && x_f16)
+    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL((tokens_to_map_kernel<_Float16, _Float16>), grid, block, 0, ctx->stream, (const _Float16*)x, (_Float16*)out, B, npad, np, D));
+  else if (precision == MHIP_PREC_F16)
+    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL((tokens_to_map_kernel<_Float16, float>), grid, block, 0, ctx->stream, (const float*)x, (_Float16*)out, B, npad, np, D));
   else
-    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(tokens_to_map_kernel<float>, grid, block, 0, ctx->stream, x, (float*)out, B, npad, np, D));
+    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL((tokens_to_map_kernel<float, float>), grid, block, 0, ctx->stream, (const float*)x, (float*)out, B, npad, np, D));
   CHECK_LAUNCH(ctx, "tokens_to_map");
   return 0;
 }
@@ -542,6 +562,12 @@ int mhip_launch_convert_rows(mhip_ctx* ctx, int precision, const void* in, float
   else
     PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(convert_rows_kernel<float>, grid, block, 0, ctx->stream, (const float*)in, out, n));
   CHECK_LAUNCH(ctx, "convert_rows");
+  return 0;
+}
+
+int mhip_launch_narrow_f16(mhip_ctx* ctx, const float* in, void* out, long long n) {
+  PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(narrow_f16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, in, (_Float16*)out, n));
+  CHECK_LAUNCH(ctx, "narrow_f16");
   return 0;
 }
 
