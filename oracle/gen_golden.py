@@ -371,6 +371,70 @@ def gen_renderer(out_dir):
     print("renderer", [len(c["text"]) for c in cases], len(doc))
 
 
+def _load_ref_xml_renderers():
+    """marie/renderer/blob_renderer.py and adlib_renderer.py, unmodified, by path (placeholders as for the text renderer, plus
+    ``marie.logging_core.predefined.default_logger`` and ``marie.renderer.renderer``)."""
+    import importlib.util
+    import types
+
+    _load_ref_text_renderer()                         # registers the placeholders and marie.renderer.ResultRenderer
+
+    class _Quiet:
+        def info(self, *a, **k):
+            pass
+
+        error = warning = debug = info
+
+    for name in ("marie.logging_core.predefined", "marie.renderer.renderer"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["marie.logging_core.predefined"].default_logger = _Quiet()
+    sys.modules["marie.renderer.renderer"].ResultRenderer = sys.modules["marie.renderer"].ResultRenderer
+    out = []
+    for fname, cls in (("blob_renderer.py", "BlobRenderer"), ("adlib_renderer.py", "AdlibRenderer")):
+        spec = importlib.util.spec_from_file_location("ref_" + fname[:-3], "/root/reference/marie/renderer/" + fname)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out.append(getattr(mod, cls))
+    return out
+
+
+XML_RENDER_CASES = [(21, 1200, 900, 5), (22, 2550, 3300, 12), (23, 640, 480, 1)]
+
+
+def xml_render_results():
+    """The page results the XML renderer goldens are made from (seeded pages + one with characters XML escapes)."""
+    from marie_icr_amd.weights import make_ocr_result
+
+    docs = [[make_ocr_result(seed, w, h, n)] for seed, w, h, n in XML_RENDER_CASES]
+    docs.append([make_ocr_result(30 + i, 900, 700, 4, page=i) for i in range(3)])
+    special = make_ocr_result(40, 800, 600, 2)
+    for word, text in zip(special["words"], ["A&B", "<tag>", "\"quoted\"", "it's", "x>y&&y<z", "\u00e9t\u00e9"]):
+        word["text"] = text
+    docs.append([special])
+    return docs
+
+
+def gen_xml_renderers(out_dir):
+    """Files the reference's own BlobRenderer / AdlibRenderer write (the on-disk formats after the path)."""
+    import copy
+    import json
+    import tempfile
+
+    BlobRenderer, AdlibRenderer = _load_ref_xml_renderers()
+    out = []
+    for results in xml_render_results():
+        frames = [np.zeros((r["meta"]["imageSize"]["height"], r["meta"]["imageSize"]["width"], 3), np.uint8) for r in results]
+        rec = {}
+        for key, cls in (("blob", BlobRenderer), ("adlib", AdlibRenderer)):
+            with tempfile.TemporaryDirectory() as td:
+                cls(config={}).render(frames, copy.deepcopy(results), td)
+                rec[key] = {name: open(os.path.join(td, name), "rb").read().decode("UTF-8") for name in sorted(os.listdir(td))}
+        out.append(rec)
+    with open(os.path.join(out_dir, "xml_renderers.json"), "w", encoding="UTF-8") as f:
+        json.dump({"documents": out}, f)
+    print("xml renderers", [sorted(d["blob"]) + sorted(d["adlib"]) for d in out])
+
+
 def _load_ref_voting_engine():
     """marie/ocr/voting_ocr_engine.py, unmodified, by path.  Its package imports (recognizer classes, PSMode, the engine base
     class, a JSON dump helper) are satisfied by placeholders — none of them is reached by the vote rules: an instance is made
@@ -504,6 +568,9 @@ def main():
         return
     if "--renderer-only" in sys.argv:
         gen_renderer(out_dir)
+        return
+    if "--xml-renderers-only" in sys.argv:
+        gen_xml_renderers(out_dir)
         return
     if "--vit-only" in sys.argv:
         gen_vit(out_dir)

@@ -60,3 +60,52 @@ def test_get_words_and_boxes():
     assert get_words_and_boxes([], 0) == ([], [])
     with pytest.raises(ValueError):
         get_words_and_boxes(res, 2)
+
+
+# ---- the two XML on-disk formats: files byte-equal to what the reference's own classes write (oracle/gen_golden.py --xml-renderers-only)
+XML_GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "xml_renderers.json"), encoding="UTF-8"))
+
+
+def _mask_date(text):
+    import re
+
+    return re.sub(r'FIELD="CreationDate" VALUE="[^"]*"', 'FIELD="CreationDate" VALUE="*"', text)
+
+
+@pytest.mark.parametrize("doc", range(len(XML_GOLD["documents"])))
+def test_xml_renderers_write_the_reference_files(doc, tmp_path):
+    import copy
+
+    from marie_icr_amd.renderer import AdlibRenderer, BlobRenderer
+    from oracle.gen_golden import xml_render_results
+
+    results = xml_render_results()[doc]
+    gold = XML_GOLD["documents"][doc]
+    frames = [np.zeros((r["meta"]["imageSize"]["height"], r["meta"]["imageSize"]["width"], 3), np.uint8) for r in results]
+    for key, cls in (("blob", BlobRenderer), ("adlib", AdlibRenderer)):
+        out = tmp_path / key
+        out.mkdir()
+        cls(config={}).render(frames, copy.deepcopy(results), str(out))
+        written = {name: (out / name).read_bytes().decode("UTF-8") for name in sorted(os.listdir(out))}
+        assert sorted(written) == sorted(gold[key])
+        for name in written:
+            assert _mask_date(written[name]) == _mask_date(gold[key][name]), (key, name)
+
+
+def test_xml_renderers_need_a_directory_and_skip_broken_pages(tmp_path):
+    from marie_icr_amd.renderer import AdlibRenderer, BlobRenderer
+    from marie_icr_amd.weights import make_ocr_result
+
+    good = make_ocr_result(5, 600, 400, 2)
+    broken = {"meta": good["meta"], "words": good["words"]}            # no "lines": the reference logs the KeyError and goes on
+    frames = [np.zeros((400, 600, 3), np.uint8)] * 2
+    for cls in (BlobRenderer, AdlibRenderer):
+        with pytest.raises(ValueError):
+            cls().render(frames, [good, good], str(tmp_path / "missing"))
+    out = tmp_path / "o"
+    out.mkdir()
+    BlobRenderer().render(frames, [broken, good], str(out))
+    assert sorted(os.listdir(out)) == ["2.BLOBS.XML"]
+    AdlibRenderer(summary_filename="s.xml").render(frames, [broken, good], str(out), filename_generator=lambda n: f"p{n}.xml")
+    assert sorted(os.listdir(out)) == ["2.BLOBS.XML", "p2.xml", "s.xml"]
+    assert 'Filename="p1.xml"' in (out / "s.xml").read_text()          # the summary lists every frame, written or not
