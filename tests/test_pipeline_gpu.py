@@ -264,3 +264,26 @@ def test_engine_batched_path_equals_per_page_loop(ctx):
                [(ln["line"], ln["text"], ln["wordids"]) for ln in got[i]["lines"]]
         assert got[i]["meta"]["page"] == i and got[i]["meta"]["format"] == "xyxy"
     ctx2.close()
+
+
+def test_example_script_writes_all_formats(tmp_path):
+    """examples/ocr_pages.py end to end on two synthetic pages (the small CRAFT + CRNN pair): results.json, the text file, one BLOBS
+    and one Adlib file per page + the summary, and a JSON status line."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "ocr_pages.py"), "--out", str(out), "--synthetic", "2", "--engine",
+                        "craft_crnn", "--precision", "f32"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    status = json.loads(r.stdout.strip().splitlines()[-1])
+    assert status["pages"] == 2 and status["words"] > 0
+    results = json.load(open(out / "results.json"))
+    assert len(results) == 2 and all(set(p) >= {"meta", "words", "lines"} for p in results)
+    assert sum(len(p["words"]) for p in results) == status["words"]
+    assert os.path.getsize(out / "results.txt") > 0
+    assert sorted(os.listdir(out / "blobs")) == ["1.BLOBS.XML", "2.BLOBS.XML"]
+    assert sorted(os.listdir(out / "adlib")) == ["1.tif.xml", "2.tif.xml", "summary.xml"]
