@@ -73,7 +73,7 @@ struct mhip_icr {
 
 namespace {
 
-constexpr int IMG_H = 32, IMG_W = 100, NFID = 20, MAXLEN = 48, STEPS = MAXLEN + 1, HID = 256;
+constexpr int IMG_H = 32, IMG_W = 100, NFID = 20, MAXLEN = 48, STEPS = MAXLEN + 1;
 
 void icr_layout(mhip_icr* m) {
   size_t o = 0;
