@@ -174,6 +174,140 @@ __global__ __launch_bounds__(512) void gemm_twogroup_kernel(Args p) {
 
 }  // namespace tg
 
+
+// ---- a third variant: FOUR waves (one per SIMD, up to 512 registers each), 128 x 128 per wave: 33 % fewer LDS fragment bytes per
+// MFMA (16 ds_read_b128 per 64 MFMAs instead of 12 per 32), fragments double-buffered across k-groups so that every read is issued a
+// whole phase before its MFMAs, one barrier per slice placed between the two k-groups (at it every wave holds the whole slice in
+// registers: the slot is free, and the next slice — issued half a slice earlier — has landed).
+namespace fw {
+
+constexpr int A_BYTES = 256 * ROWB, STAGE = 512 * ROWB;
+
+__global__ __launch_bounds__(256) void gemm_fourwave_kernel(tg::Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int mt, nt;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    nt = L % p.ntiles;
+    mt = L / p.ntiles;
+  }
+  // staging: instruction (4 q + wave) of an operand covers its rows 8 (4 q + wave) .. + 7; swizzle term (row >> 1) & 7 = 4 (wave & 1) + (r >> 1)
+  const int r8 = lane >> 3;
+  const int lane_off = (((lane & 7) ^ (4 * (wave & 1) + (r8 >> 1))) << 4);
+  const size_t rowb = (size_t)p.K * 2;
+  // uniform tile bases + 32-bit per-lane offsets (sixteen 64-bit pointers per lane spill: the fragments take 128 registers)
+  const char* a_tile = p.A + (size_t)mt * 256 * rowb;
+  const char* w_tile = p.W + (size_t)nt * 256 * rowb;
+  unsigned a_vo[8], w_vo[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = (4 * q + wave) * 8 + r8;
+    a_vo[q] = (unsigned)min(row, p.M - 1 - mt * 256) * (unsigned)rowb + lane_off;
+    w_vo[q] = (unsigned)min(row, p.N - 1 - nt * 256) * (unsigned)rowb + lane_off;
+  }
+  unsigned kA = 0, kW = 0;                     // K byte offsets of the next A half / W half to issue (the halves of a slice go out at different times)
+  auto chunk = [&](int slot, int g) {       // g < 8: A instruction g of this wave, else W instruction g - 8
+    if (g < 8) glds16(a_tile + (a_vo[g] + kA), smem + slot * STAGE + (4 * g + wave) * 1024);
+    else glds16(w_tile + (w_vo[g - 8] + kW), smem + slot * STAGE + A_BYTES + (4 * (g - 8) + wave) * 1024);
+  };
+  const int frow = lane & 15, fg = lane >> 4;
+  int a_off, b_off[2];
+  {
+    const int ra = wr * 128 + frow;
+    a_off = ra * ROWB + ((fg ^ ((ra >> 1) & 7)) << 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int rb = wc * 128 + 8 * (frow >> 2) + 4 * h + (frow & 3);
+      b_off[h] = A_BYTES + rb * ROWB + ((fg ^ ((rb >> 1) & 7)) << 4);
+    }
+  }
+  float4v acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+  const int ns = p.nslices;
+  half8 a0[8], b0[8], a1[8], b1[8];
+  auto load_frags = [&](half8 (&a)[8], half8 (&b)[8], const char* sb, int kg) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = *(const half8*)(sb + (b_off[j & 1] ^ (kg << 6)) + (j >> 1) * (32 * ROWB));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = *(const half8*)(sb + (a_off ^ (kg << 6)) + i * (16 * ROWB));
+  };
+  auto mfmas = [&](const half8 (&a)[8], const half8 (&b)[8]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: slice 0 landed, its first k-group in registers, the A half of slice 1 on its way
+#pragma unroll
+  for (int g = 0; g < 16; ++g) chunk(0, g);
+  kA += ROWB; kW += ROWB;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  load_frags(a0, b0, smem, 0);
+  if (ns > 1) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) chunk(1, g);
+    kA += ROWB;
+  }
+#pragma unroll 1
+  for (int t = 0; t < ns; ++t) {
+    const char* sb = smem + (t & 1) * STAGE;
+    const char* sn = smem + ((t + 1) & 1) * STAGE;
+    // phase A: the W half of slice t + 1; fragments of (t, k-group 1); MFMAs of k-group 0
+    if (t + 1 < ns) {
+#pragma unroll
+      for (int g = 8; g < 16; ++g) chunk((t + 1) & 1, g);
+      kW += ROWB;
+    }
+    load_frags(a1, b1, sb, 1);
+    mfmas(a0, b0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // slice t + 1 landed; slice t is in registers
+    __builtin_amdgcn_s_barrier();
+    // phase B: the A half of slice t + 2 into the slot of slice t; fragments of (t + 1, k-group 0); MFMAs of k-group 1
+    if (t + 2 < ns) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) chunk(t & 1, g);
+      kA += ROWB;
+    }
+    if (t + 1 < ns) load_frags(a0, b0, sn, 0);
+    mfmas(a1, b1);
+  }
+
+  // ---- epilogue: bias, f16, 16-byte stores straight from the (transposed) accumulators
+  const int row0 = mt * 256 + wr * 128 + frow, col0 = nt * 256 + wc * 128 + 8 * fg;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int col = col0 + 32 * jj;
+    float bi[8];
+    {
+      const float4v q0 = *(const float4v*)(p.bias + min(col, p.N - 8)), q1 = *(const float4v*)(p.bias + min(col, p.N - 8) + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bi[e] = q0[e]; bi[4 + e] = q1[e]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = row0 + 16 * i;
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (_Float16)(acc[i][2 * jj + (e >> 2)][e & 3] + bi[e]);
+      if (row < p.M && col < p.N) *(half8*)(p.out + ((size_t)row * p.N + col) * 2) = o;
+    }
+  }
+}
+
+}  // namespace fw
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 __global__ void fill_kernel(_Float16* p, size_t n, unsigned seed, float amp) {
@@ -209,6 +343,7 @@ int main(int argc, char** argv) {
   unsigned* bad; float* maxd;
   CK(hipMalloc((void**)&bad, 4)); CK(hipMalloc((void**)&maxd, 4));
   (void)hipFuncSetAttribute((const void*)tg::gemm_twogroup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tg::STAGE);
+  (void)hipFuncSetAttribute((const void*)fw::gemm_fourwave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * fw::STAGE);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (const Shape& s : shapes) {
@@ -218,12 +353,14 @@ int main(int argc, char** argv) {
     a.A = (const char*)A; a.W = (const char*)W; a.bias = bias; a.out = (char*)C1; a.M = rows; a.N = s.N; a.K = s.K; a.nslices = s.K / 64;
     a.ntiles = (s.N + 255) / 256;
     const int grid = ((rows + 255) / 256) * a.ntiles;
-    float ms[2] = {0, 0};
+    float ms[3] = {0, 0, 0};
+    const int nvar = getenv("GB_ONLY2") ? 2 : 3;
     for (int it = -1; it < iters; ++it)
-      for (int which = 0; which < 2; ++which) {
+      for (int which = 0; which < nvar; ++which) {
         CK(hipEventRecord(e0, ctx.stream));
         if (which == 0) { if (mhip_launch_conv_igemm(&ctx, MHIP_PREC_F16, d)) return 1; }
-        else hipLaunchKernelGGL(tg::gemm_twogroup_kernel, dim3(grid), dim3(512), 2 * tg::STAGE, ctx.stream, a);
+        else if (which == 1) hipLaunchKernelGGL(tg::gemm_twogroup_kernel, dim3(grid), dim3(512), 2 * tg::STAGE, ctx.stream, a);
+        else hipLaunchKernelGGL(fw::gemm_fourwave_kernel, dim3(grid), dim3(256), 2 * fw::STAGE, ctx.stream, a);
         CK(hipEventRecord(e1, ctx.stream));
         CK(hipStreamSynchronize(ctx.stream));
         float t = 0;
@@ -235,8 +372,8 @@ int main(int argc, char** argv) {
     unsigned hb = 0; float hm = 0;
     CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hm, maxd, 4, hipMemcpyDeviceToHost));
     const double fl = 2.0 * rows * (double)s.K * s.N;
-    printf("%-14s production %8.3f ms %7.1f TFLOP/s | two-group %8.3f ms %7.1f TFLOP/s | %u elements differ (max %.4g)\n", s.name, ms[0],
-           fl / ms[0] * 1e-9, ms[1], fl / ms[1] * 1e-9, hb, hm);
+    printf("%-14s production %8.3f ms %7.1f TFLOP/s | two-group %8.3f ms %7.1f | four-wave %8.3f ms %7.1f TFLOP/s | last variant: %u elements differ (max %.4g)\n",
+           s.name, ms[0], fl / ms[0] * 1e-9, ms[1], fl / ms[1] * 1e-9, ms[2], nvar > 2 ? fl / ms[2] * 1e-9 : 0.0, hb, hm);
   }
   return 0;
 }
