@@ -151,6 +151,21 @@ def host_cores_physical():
     return max(1, phys), max(1, len(aff))
 
 
+def _edit_rate(refs, hyps) -> float:
+    """sum of Levenshtein distances / sum of reference lengths (the reference's char-error definition)."""
+    dist = total = 0
+    for r, h in zip(refs, hyps):
+        prev = list(range(len(h) + 1))
+        for i, a in enumerate(r, 1):
+            cur = [i]
+            for j, b in enumerate(h, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (a != b)))
+            prev = cur
+        dist += prev[-1]
+        total += len(r)
+    return dist / max(1, total)
+
+
 def _iou_match(ref, got, bar):
     if len(ref) == 0 or len(got) == 0:
         return 0.0
@@ -221,6 +236,9 @@ def cpu_baseline_dit_trocr(dit_state, trocr_state, trocr_dims, decode_len, n_lin
                         "matched_iou_0.999": _iou_match(boxes, gb, 0.999), "matched_iou_0.99": _iou_match(boxes, gb, 0.99),
                         "matched_iou_0.9": _iou_match(boxes, gb, 0.9), "matched_iou_0.5": _iou_match(boxes, gb, 0.5)},
               "trocr": {"crops": k, "hypotheses_token_equal": int(sum(equal)),
+                        # BASELINE.json's second metric ("char-error vs ref"): Levenshtein distance / reference length; the
+                        # seeded models have no real vocabulary, so the symbols compared are the token ids
+                        "symbol_error_rate": _edit_rate([list(map(int, r[0])) for r in ref], [list(map(int, g[0])) for g in got]),
                         "max_abs_score_diff_where_equal": max([abs(g[1] - r[1]) for g, r, e in zip(got, ref, equal) if e] or [0.0]),
                         "oracle_best_minus_oracle_score_of_gpu_hypothesis": [float(r[1] - s_) for r, s_ in zip(ref, own)]},
               "note": "f16 operands re-order near-tied discrete choices of a random-weight model; the fp32 bars (911/911 boxes "

@@ -85,3 +85,15 @@ def test_all_legs_run_and_the_process_exits_cleanly():
     assert eng["fixed_lines"]["value"] > 0 and eng["fixed_lines"]["page_batch"] == 4
     assert eng["fixed_lines"]["lines_per_page"] == 40
     assert line["overlay"]["value"] > 0
+
+
+def test_symbol_error_rate_is_levenshtein_over_reference_length():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._edit_rate([[1, 2, 3, 4]], [[1, 2, 4]]) == 0.25                 # one deletion
+    assert bench._edit_rate([[1, 2], [3]], [[1, 2], [3]]) == 0.0
+    assert bench._edit_rate([[1, 2, 3]], [[9, 9, 9, 9]]) == pytest.approx(4 / 3)  # three substitutions + one insertion
+    assert bench._edit_rate([[5, 6]], [[]]) == 1.0
