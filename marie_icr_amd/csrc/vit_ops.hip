@@ -87,7 +87,7 @@ struct AttnArgs {
 
 constexpr int AT_THREADS = 256, AT_QB = 128, AT_KT = 64;
 constexpr int AT_TILE = AT_KT * 128;                 // bytes of a K tile (64 keys x 64 f16) == of a V^T tile (64 d x 64 keys)
-constexpr int AT_STAGE = 2 * AT_TILE, AT_NSTAGE = 3;
+constexpr int AT_STAGE = 2 * AT_TILE, AT_NSTAGE = 2;
 
 __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -126,12 +126,15 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
     ksrc[q] = p.k + ((krow0 + key) * p.ldk + h * HD + lc * 8) * 2;
     vsrc[q] = p.vt + (((size_t)h * HD + R) * p.ldv + krow0 + lc * 8) * 2;
   }
-  auto stage = [&](int t, int slot) {
+  // tiles are staged in order: the source pointers run along (a multiply-add per tile and pointer cost ~30 VALU instructions of
+  // a loop that is VALU-bound)
+  const size_t kstep = (size_t)AT_KT * p.ldk * 2;
+  auto stage = [&](int slot) {
     char* la = smem + slot * AT_STAGE + wave * 1024;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) glds16(ksrc[q] + (size_t)t * AT_KT * p.ldk * 2, la + q * 4096);
+    for (int q = 0; q < 2; ++q) { glds16(ksrc[q], la + q * 4096); ksrc[q] += kstep; }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) glds16(vsrc[q] + (size_t)t * AT_KT * 2, la + AT_TILE + q * 4096);
+    for (int q = 0; q < 2; ++q) { glds16(vsrc[q], la + AT_TILE + q * 4096); vsrc[q] += AT_KT * 2; }
   };
 
   float4v acc_o[4][2];
@@ -146,7 +149,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
   // and wave) exceeds its MFMA work (512).  O / l at the end is independent of the reference.
   constexpr float RESCALE_AT = 8.f;
   float4v negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // -m of this lane's query, broadcast: the MFMA's C operand
-  float lrow[2] = {0.f, 0.f};
+  // The soft-max denominators come from the matrix cores as well: a 17th "value row" of ones, i.e. an A operand whose row 0 is
+  // all ones (a constant fragment, no LDS), gives l[query] = sum of the SAME f16-rounded probabilities the numerator uses in
+  // row 0 of acc_l (lanes g = 0, element 0).  That takes the 32 adds per tile (hipcc packs them into v_pk_add_f32, which
+  // costs more than two plain adds beside MFMAs) out of the VALU stream for 4 more MFMAs per tile.
+  const half8 ones = n == 0 ? (half8){1, 1, 1, 1, 1, 1, 1, 1} : (half8){0, 0, 0, 0, 0, 0, 0, 0};
+  float4v acc_l[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
   // fragment read offsets (row = n within a 16-row tile, logical slot = g (+4 for the second k step))
   int foff[4];
@@ -157,14 +165,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
   }
 
   const int ntiles = (p.n_keys + AT_KT - 1) / AT_KT;
-  stage(0, 0);
-  if (ntiles > 1) stage(1, 1);
-  int slot = 0, fill = 2;
+  stage(0);
+  int slot = 0, fill = 1;
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < ntiles) stage(t + 2, fill);
+    if (t + 1 < ntiles) stage(fill);
     const char* sk = smem + slot * AT_STAGE;
     const char* sv = sk + AT_TILE;
 
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
         const float d = t == 0 ? tmax[qt] : (tmax[qt] > RESCALE_AT ? tmax[qt] : 0.f);
         const float alpha = t == 0 ? 0.f : __builtin_amdgcn_exp2f(-d);
         negm[qt] -= (float4v){d, d, d, d};
-        lrow[qt] *= alpha;
+        acc_l[qt] *= alpha;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
 #pragma unroll
@@ -224,18 +230,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
       }
     }
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float sum = 0.f;
+    for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[kt][qt][r]);
-          sum += e;
-          pb[qt][kt >> 1][(kt & 1) * 4 + r] = (_Float16)e;
-        }
-      lrow[qt] += sum;
-    }
+        for (int r = 0; r < 4; ++r) pb[qt][kt >> 1][(kt & 1) * 4 + r] = (_Float16)__builtin_amdgcn_exp2f(s[kt][qt][r]);
     // ---- O^T += V^T P^T ----------------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -246,6 +245,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
         acc_o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[0][c], acc_o[dt][0], 0, 0, 0);
         acc_o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[1][c], acc_o[dt][1], 0, 0, 0);
       }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      acc_l[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pb[0][c], acc_l[0], 0, 0, 0);
+      acc_l[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pb[1][c], acc_l[1], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
     slot = slot == AT_NSTAGE - 1 ? 0 : slot + 1;
     fill = fill == AT_NSTAGE - 1 ? 0 : fill + 1;
@@ -253,10 +257,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_flash_f16_kernel(AttnArgs p) 
   // ---- normalise and store: lane holds O^T[d = 16 dt + 4 g + r][query n] -> 4 consecutive d of one output row ------
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = lrow[qt];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float inv = 1.f / l;
+    const float inv = 1.f / __shfl(acc_l[qt][0], n);          // row 0 of the ones tile lives in lanes g = 0
+
     if (qb * AT_QB + wave * 32 + qt * 16 + n >= p.npad_q) continue;   // the last block may reach into the next image
     char* orow = p.out + ((qrow0 + qt * 16 + n) * p.ldo + h * HD) * 2;
 #pragma unroll
