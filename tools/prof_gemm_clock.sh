@@ -1,5 +1,5 @@
 # Effective clock and MFMA-busy share of conv_igemm<256> on the ViT GEMM shapes: rocprofv3 --pmc passes over tools/ubench/gb_prod
-# (counters only with --kernel-trace, one group per pass).  GRBM_GUI_ACTIVE / 8 / wall = clock; SQ_VALU_MFMA_BUSY_CYCLES summed over
+# (counters only with --kernel-trace, one group per pass).  Build the binary here first: (cd tools/ubench && ./build_gb.sh prod).  GRBM_GUI_ACTIVE / 8 / wall = clock; SQ_VALU_MFMA_BUSY_CYCLES summed over
 # the 1024 SIMDs / (1024 x GRBM_GUI_ACTIVE / 8) = share of cycles the matrix cores are busy.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT/tools/ubench

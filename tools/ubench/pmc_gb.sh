@@ -1,4 +1,4 @@
-# HBM-side traffic of gemm_bench variants: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one counter per pass, kernel trace only)
+# Build the variants here first (cd tools/ubench && ./build_gb.sh prod [-D...]).  HBM-side traffic of gemm_bench variants: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one counter per pass, kernel trace only)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT/tools/ubench
 for v in "$@"; do
