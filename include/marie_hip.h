@@ -52,6 +52,21 @@ int mhip_device_info(mhip_ctx* ctx, char* arch, size_t arch_len, int* cu_count, 
 /* Device-to-device copy on the ctx stream (e.g. weight arena <-> an RCCL broadcast buffer). */
 int mhip_memcpy_dev(mhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 
+/* Phase gate: orders two streams that are fed by two host threads.  replaces: nothing in the reference — its page loop is
+ * serial (marie/ocr/ocr_engine.py:172-221: detect, then recognize, page by page); here the detector of page batch k + 1 runs
+ * under the HBM-bound decode phase of the recognizer of batch k, and the gate is where that phase starts.
+ *   mhip_gate_signal  records an event on ctx's stream and counts it (signal n);
+ *   mhip_gate_wait    blocks the calling thread until signal `seq` exists (at most timeout_ms), then makes ctx's stream wait
+ *                     for it: returns 1 (stream ordered), 0 (gate open or timed out: the caller proceeds unordered), < 0 error;
+ *   mhip_gate_open    1: every present and future wait returns 0 at once (error / shutdown path), 0: closes it again.      */
+typedef struct mhip_gate mhip_gate;
+int mhip_gate_create(mhip_ctx* ctx, mhip_gate** out);
+int mhip_gate_destroy(mhip_gate* g);
+int mhip_gate_signal(mhip_gate* g, mhip_ctx* ctx);
+long long mhip_gate_count(mhip_gate* g);
+int mhip_gate_open(mhip_gate* g, int open);
+int mhip_gate_wait(mhip_gate* g, mhip_ctx* ctx, long long seq, int timeout_ms);
+
 /* Per-kernel timing with HIP events on the ctx stream (bench.py's roofline leg).
  * replaces: marie/logging_core/profile.py TimeContextCuda around model calls.
  * While enabled every kernel launch is bracketed by an event pair; mhip_profile_read
@@ -370,6 +385,9 @@ int mhip_trocr_finalize(mhip_trocr* m);
 int mhip_trocr_alloc_arena(mhip_trocr* m);
 int mhip_trocr_arena(mhip_trocr* m, int which /* 0 encoder, 1 decoder */, void** arena_dev, size_t* bytes);
 size_t mhip_trocr_workspace_bytes(mhip_trocr* m, int n);
+/* `gate` (may be NULL) is signalled inside every generate call at the point of the stream where the image encoder ends and
+ * the autoregressive decode begins (TextRecognitionGenerator._generate's step loop, generator.py:182-362).  The caller owns it. */
+int mhip_trocr_set_decode_gate(mhip_trocr* m, mhip_gate* gate);
 /* n device crops u8 [img][img][3] -> best hypothesis per crop: tokens_out [n][max_len + 1] (eos included, pad-filled),
  * lengths_out [n], scores_out [n] = length-normalised log-probability (the reference reports exp(score)).               */
 int mhip_trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int swap_rb, int32_t* tokens_out,

@@ -27,6 +27,12 @@ _SIGNATURES = (
     ("mhip_synchronize", _i, [_vp]),
     ("mhip_device_info", _i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)]),
     ("mhip_memcpy_dev", _i, [_vp, _vp, _vp, _sz]),
+    ("mhip_gate_create", _i, [_vp, C.POINTER(_vp)]),
+    ("mhip_gate_destroy", _i, [_vp]),
+    ("mhip_gate_signal", _i, [_vp, _vp]),
+    ("mhip_gate_count", C.c_longlong, [_vp]),
+    ("mhip_gate_open", _i, [_vp, _i]),
+    ("mhip_gate_wait", _i, [_vp, _vp, C.c_longlong, _i]),
     ("mhip_profile_enable", _i, [_vp, _i]),
     ("mhip_profile_reset", _i, [_vp]),
     ("mhip_profile_read", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -102,6 +108,7 @@ _SIGNATURES = (
     ("mhip_trocr_alloc_arena", _i, [_vp]),
     ("mhip_trocr_arena", _i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     ("mhip_trocr_workspace_bytes", _sz, [_vp, _i]),
+    ("mhip_trocr_set_decode_gate", _i, [_vp, _vp]),
     ("mhip_trocr_generate", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     ("mhip_trocr_generate_host", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("mhip_trocr_generate_fragments", _i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -270,11 +277,52 @@ class Context:
                                                           "flops": fl.value}
         return out
 
+    def make_gate(self) -> "PhaseGate":
+        return PhaseGate(self)
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
             for child in list(getattr(self, "_children", ())):
                 child.close()
             self.lib.mhip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PhaseGate:
+    """``mhip_gate`` (include/marie_hip.h): one thread says where a phase starts in its stream (``signal``), another makes its
+    own stream wait for that point (``wait``).  ``open()`` lets every waiter through — the error path."""
+
+    def __init__(self, ctx: Context):
+        self.ctx, self.lib = ctx, ctx.lib
+        h = C.c_void_p()
+        check(ctx.h, self.lib.mhip_gate_create(ctx.h, C.byref(h)), "mhip_gate_create")
+        self.h = h
+        ctx.adopt(self)
+
+    def signal(self, ctx: Context):
+        check(ctx.h, self.lib.mhip_gate_signal(self.h, ctx.h), "mhip_gate_signal")
+
+    def count(self) -> int:
+        return int(self.lib.mhip_gate_count(self.h))
+
+    def open(self, opened: bool = True):
+        self.lib.mhip_gate_open(self.h, 1 if opened else 0)
+
+    def wait(self, ctx: Context, seq: int, timeout_ms: int = 60000) -> bool:
+        rc = self.lib.mhip_gate_wait(self.h, ctx.h, int(seq), int(timeout_ms))
+        if rc < 0:
+            check(ctx.h, rc, "mhip_gate_wait")
+        return rc == 1
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.mhip_gate_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

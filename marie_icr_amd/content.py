@@ -18,6 +18,11 @@ def content_extents(ctx, page_dev_ptr: int, h: int, w: int, rects_xywh, content_
     rects = np.ascontiguousarray(np.asarray(rects_xywh, np.int32).reshape(-1, 4))
     out = np.zeros((len(rects), 5), np.int32)
     if len(rects):
+        import torch
+
+        # the launches go to the caller's current stream (the one the page was uploaded / written on), not to whatever stream the
+        # context last held — that one may belong to a call that has ended
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         check(ctx.h, ctx.lib.mhip_content_extents(ctx.h, C.c_void_p(page_dev_ptr), h, w, rects.ctypes.data_as(C.c_void_p), len(rects),
                                                   1 if content_aware else 0, out.ctypes.data_as(C.c_void_p)), "mhip_content_extents")
     return out

@@ -162,13 +162,20 @@ class BoxProcessorCraft:
             raise MarieHipError("BoxProcessorCraft here is the MI355X path; cuda=False has no implementation")
         self.work_dir = work_dir
         self.cuda = cuda
+        if state is None:
+            # craft_box_processor.py:248,263: models_dir defaults to <model zoo>/craft, the checkpoint is craft_mlt_25k.pth in
+            # it; looked up before a device context exists, so that a missing checkpoint is the loader's error on any machine
+            from .constants import __model_path__
+
+            models_dir = os.path.join(__model_path__, "craft") if models_dir is None else models_dir
+            path = os.path.join(models_dir, "craft_mlt_25k.pth")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"File not found : {path}")
         self.ctx = ctx or Context(device_id)
         if state is None:
-            if models_dir is None:
-                raise ValueError("either `state` or `models_dir` is required")
             import torch
 
-            sd = torch.load(os.path.join(models_dir, "craft_mlt_25k.pth"), map_location="cpu", weights_only=True)
+            sd = torch.load(path, map_location="cpu", weights_only=True)
             state = {k: v.numpy() for k, v in sd.items()}
         prec = {"f16": PREC_F16, "fp16": PREC_F16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
         self.model = CraftModel(self.ctx, state, precision=prec)

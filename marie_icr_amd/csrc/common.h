@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,8 +62,12 @@ struct mhip_ctx {
 int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...);
 // Teardown: wait for the device, not for ctx->stream — the caller's stream (a torch stream handed in by mhip_set_stream) may
 // already be gone when an object is destroyed late (interpreter shutdown), and synchronising a dead handle aborts the process
-inline void mhip_quiesce() { (void)hipDeviceSynchronize(); }
+inline void mhip_quiesce(const mhip_ctx* ctx) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // the device this object lives on, not whatever the calling thread last used
+  (void)hipDeviceSynchronize();
+}
 int mhip_ensure_workspace(mhip_ctx* ctx, size_t bytes);
+extern "C" int mhip_gate_signal(mhip_gate* g, mhip_ctx* ctx);   // phase_gate.hip
 void mhip_prof_begin(mhip_ctx* ctx, int kid, hipEvent_t* e0);
 void mhip_prof_end(mhip_ctx* ctx, int kid, hipEvent_t e0);
 
@@ -289,7 +294,6 @@ struct CrossAbsorbDesc {
   int ldq = 0;
   const void* E = nullptr;     // [crops][kv_rows][enc_dim] f16 encoder tokens
   int kv_rows = 0, n_keys = 0, enc_dim = 0;
-  int tiled = 0;               // 1: E is [key tile][crop][32 keys][enc_dim] (mhip_cross_tile_rows), kv_rows unused
   const void* wkt = nullptr;   // [heads][enc_dim][64] f16: W_k[h*64 + j][d] * log2(e) at [h][d][j]
   const void* wv = nullptr;    // [heads*64][enc_dim] f16 (the checkpoint's layout)
   const float* bv = nullptr;   // [heads*64]

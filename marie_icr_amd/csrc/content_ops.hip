@@ -186,6 +186,7 @@ extern "C" int mhip_content_extents(mhip_ctx* ctx, const uint8_t* page_dev, int 
                                     int content_aware, int32_t* ext_host) {
   if (!ctx || !page_dev || !rects_xywh_host || !ext_host || h < 1 || w < 1 || n < 0) return MHIP_EINVAL;
   if (n == 0) return MHIP_OK;
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<ContentRect> rects(n);
   unsigned long long total = 0;
   long long max_area = 0;

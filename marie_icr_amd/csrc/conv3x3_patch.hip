@@ -291,15 +291,14 @@ int launch_patch(mhip_ctx* ctx, const IgemmArgs& a, int pool, int pw_shift, int 
   const long long blocks = (long long)a.B * a.tiles_x * a.tiles_y * a.ntiles;
   if (blocks > 0x7fffffffLL) return mhip_fail(ctx, MHIP_EINVAL, "conv3x3_patch: grid too large");
   dim3 grid((unsigned)blocks), block(NTHREADS);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_set;
+  std::call_once(attr_set, [&] {
 #define SETATTR(...) (void)hipFuncSetAttribute((const void*)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)
     SETATTR(conv3x3_patch_kernel<T, POOL_NONE, BN_>);
     SETATTR(conv3x3_patch_kernel<T, POOL_2x2, BN_>);
     SETATTR(conv3x3_patch_kernel<T, POOL_2x1, BN_>);
 #undef SETATTR
-    attr_set = true;
-  }
+  });
   switch (pool) {
     case POOL_NONE:
       PROF_LAUNCH(ctx, MHIP_K_IGEMM_PATCH, hipLaunchKernelGGL((conv3x3_patch_kernel<T, POOL_NONE, BN_>), grid, block, lds,

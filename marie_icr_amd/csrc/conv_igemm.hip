@@ -539,16 +539,15 @@ int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
   constexpr int KID = BN_ == 64 ? MHIP_K_IGEMM_T64 : (BN_ == 128 ? MHIP_K_IGEMM_T128 : MHIP_K_IGEMM_T256);
   dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(NTHREADS);
   const size_t lds = Cfg<BN_>::LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_set;
+  std::call_once(attr_set, [&] {
 #define SETATTR(...) (void)hipFuncSetAttribute((const void*)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
     SETATTR(conv_igemm_kernel<T, POOL_NONE, BN_, false>);
     SETATTR(conv_igemm_kernel<T, POOL_2x2, BN_, false>);
     SETATTR(conv_igemm_kernel<T, POOL_2x1, BN_, false>);
     SETATTR(conv_igemm_kernel<T, POOL_NONE, BN_, true>);
 #undef SETATTR
-    attr_set = true;
-  }
+  });
   if (a.in2) {
     PROF_LAUNCH(ctx, KID,
                 hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, BN_, true>), grid, block, lds, ctx->stream, a));
@@ -578,11 +577,10 @@ template <typename T>
 int launch_small(mhip_ctx* ctx, const IgemmArgs& a) {
   dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(NTHREADS);
   const size_t lds = Cfg<1128>::LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_set;
+  std::call_once(attr_set, [&] {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, POOL_NONE, 1128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   PROF_LAUNCH(ctx, MHIP_K_IGEMM_S128,
               hipLaunchKernelGGL((conv_igemm_kernel<T, POOL_NONE, 1128, false>), grid, block, lds, ctx->stream, a));
   hipError_t e = hipGetLastError();

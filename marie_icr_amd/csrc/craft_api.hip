@@ -124,7 +124,7 @@ extern "C" int mhip_craft_create(mhip_ctx* ctx, int precision, mhip_craft** out)
 
 extern "C" int mhip_craft_destroy(mhip_craft* m) {
   if (!m) return MHIP_OK;
-  mhip_quiesce();
+  mhip_quiesce(m->ctx);
   if (m->arena) (void)hipFree(m->arena);
   if (m->hpin) (void)hipHostFree(m->hpin);
   delete m;

@@ -51,7 +51,7 @@ extern "C" int mhip_init(int device_id, mhip_ctx** out) {
 extern "C" int mhip_destroy(mhip_ctx* ctx) {
   if (!ctx) return MHIP_OK;
   (void)hipSetDevice(ctx->device);
-  mhip_quiesce();
+  mhip_quiesce(ctx);
   for (auto& s : ctx->prof)
     for (auto& p : s.pending) {
       (void)hipEventDestroy(p.first);
@@ -325,7 +325,7 @@ extern "C" int mhip_crnn_create(mhip_ctx* ctx, int precision, int num_class, mhi
 extern "C" int mhip_crnn_destroy(mhip_crnn* m) {
   if (!m) return MHIP_OK;
   if (m->arena) {
-    mhip_quiesce();
+    mhip_quiesce(m->ctx);
     (void)hipFree(m->arena);
   }
   delete m;

@@ -380,16 +380,14 @@ int launch_ed(mhip_ctx* ctx, const CrossAbsorbDesc& d) {
   a.E = (const _Float16*)d.E; a.qt = (const _Float16*)d.qt; a.ct = (_Float16*)d.ct;
   constexpr int TILE_B = TK * ED * 2;
   a.n_keys = d.n_keys; a.heads = d.heads;
-  if (d.tiled) { a.crop_stride = TILE_B; a.tile_stride = (size_t)d.crops * TILE_B; }
-  else { a.crop_stride = (size_t)d.kv_rows * ED * 2; a.tile_stride = TILE_B; }
+  a.crop_stride = (size_t)d.kv_rows * ED * 2; a.tile_stride = TILE_B;
   const size_t lds = (size_t)cross_slots(ED, d.beam) * TILE_B + (size_t)d.beam * 4096;
 #define CROSS_LAUNCH(WV)                                                                                                       \
   do {                                                                                                                         \
-    static bool attr = false;                                                                                                  \
-    if (!attr) {                                                                                                               \
+    static std::once_flag attr;                                                                                                \
+    std::call_once(attr, [&] {                                                                                                 \
       (void)hipFuncSetAttribute((const void*)cross_attn_kernel<ED, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr = true;                                                                                                             \
-    }                                                                                                                          \
+    });                                                                                                                        \
     PROF_LAUNCH(ctx, MHIP_K_CROSS_ATTN,                                                                                        \
                 hipLaunchKernelGGL((cross_attn_kernel<ED, WV>), dim3(d.crops), dim3(128 * WV), lds, ctx->stream, a));          \
   } while (0)

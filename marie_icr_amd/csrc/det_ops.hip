@@ -550,12 +550,11 @@ int mhip_launch_rpn_proposals(mhip_ctx* ctx, const RpnDesc& d) {
   a.boxes = d.lvl_boxes; a.scores = d.lvl_scores; a.counts = d.lvl_counts;
   const int lds1 = 32768 + 1000 * 16 * 8;
   const int lds2 = 8192 * 8;
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr;
+  std::call_once(attr, [&] {
     (void)hipFuncSetAttribute((const void*)rpn_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     (void)hipFuncSetAttribute((const void*)rpn_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-    attr = true;
-  }
+  });
   PROF_LAUNCH(ctx, MHIP_K_DET_OPS, {
     hipLaunchKernelGGL(rpn_level_kernel, dim3(5, d.images), dim3(RPN_THREADS), lds1, ctx->stream, a);
     hipLaunchKernelGGL(rpn_merge_kernel, dim3(d.images), dim3(1024), lds2, ctx->stream, d.lvl_boxes, d.lvl_scores,
@@ -584,11 +583,10 @@ int mhip_launch_det_final(mhip_ctx* ctx, const DetFinalDesc& d) {
   a.score_thr = d.score_thr; a.nms_thr = d.nms_thr; a.max_det = d.max_det;
   a.out_boxes = d.out_boxes; a.out_scores = d.out_scores; a.out_count = d.out_count;
   const int lds = 8192 + 16384 + 4096 + 1024 + 1000 * 16 * 8;
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr;
+  std::call_once(attr, [&] {
     (void)hipFuncSetAttribute((const void*)det_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr = true;
-  }
+  });
   PROF_LAUNCH(ctx, MHIP_K_DET_OPS, hipLaunchKernelGGL(det_final_kernel, dim3(d.images), dim3(1024), lds, ctx->stream, a));
   CHECK_LAUNCH(ctx, "det_final");
   return 0;

@@ -127,7 +127,7 @@ extern "C" int mhip_dit_create(mhip_ctx* ctx, int precision, const mhip_dit_conf
 
 extern "C" int mhip_dit_destroy(mhip_dit* m) {
   if (!m) return MHIP_OK;
-  mhip_quiesce();
+  mhip_quiesce(m->ctx);
   mhip_vit_destroy(m->vit);
   m->arena.release();
   delete m;

@@ -163,7 +163,7 @@ extern "C" int mhip_icr_create(mhip_ctx* ctx, int precision, int num_class, mhip
 
 extern "C" int mhip_icr_destroy(mhip_icr* m) {
   if (!m) return MHIP_OK;
-  mhip_quiesce();
+  mhip_quiesce(m->ctx);
   if (m->arena) (void)hipFree(m->arena);
   delete m;
   return MHIP_OK;

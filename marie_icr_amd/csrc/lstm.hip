@@ -322,12 +322,11 @@ int mhip_launch_lstm_rec(mhip_ctx* ctx, int precision, const float* xproj, const
   if (B < 1 || T < 1) return mhip_fail(ctx, MHIP_EINVAL, "lstm: bad shape B=%d T=%d", B, T);
   dim3 grid((B + ROWS - 1) / ROWS, 2), block(256);
   if (precision == MHIP_PREC_F16) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
       (void)hipFuncSetAttribute((const void*)lstm_rec_resident_f16, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 RES_LDS_BYTES);
-      attr_set = true;
-    }
+    });
     PROF_LAUNCH(ctx, MHIP_K_LSTM_REC,
                 hipLaunchKernelGGL(lstm_rec_resident_f16, grid, block, RES_LDS_BYTES, ctx->stream, xproj,
                                    (const half8*)wpack, (_Float16*)hseq, B, T));

@@ -103,7 +103,7 @@ extern "C" int mhip_overlay_create(mhip_ctx* ctx, int precision, int ngf, mhip_o
 
 extern "C" int mhip_overlay_destroy(mhip_overlay* m) {
   if (!m) return MHIP_OK;
-  mhip_quiesce();
+  mhip_quiesce(m->ctx);
   m->arena.release();
   delete m;
   return MHIP_OK;
@@ -189,12 +189,17 @@ extern "C" int mhip_overlay_padded_shape(int h, int w, int* H, int* W) {
 }
 
 static size_t overlay_ws_bytes(const mhip_overlay* m, int H, int W) {
-  const size_t es = m->esz(), P = (size_t)H * W, ngf = m->ngf;
-  // full resolution: x4, three ngf-channel maps (stem / padded copies / conv outputs) incl. the 6-pixel frame, zero-insert canvas,
-  // output [P][8]; half resolution and below are bounded by the same again
-  size_t b = P * 4 * es + 4 * ((size_t)(H + 8) * (W + 8) * ngf * es) + P * 8 * es + P * 192 * es;
-  b += 8 * ((size_t)(H / 2 + 8) * (W / 2 + 8) * 2 * ngf * es);
-  return 2 * b + (1 << 20);
+  // exactly what overlay_run carves, in its order (every take is rounded up to 256 bytes)
+  const size_t es = m->esz(), P = (size_t)H * W, ngf = m->ngf, G = 2 * ngf, Hh = H / 2, Wh = W / 2;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  size_t b = up(3 * 2048 * 4);                              // stats
+  b += up(P * 4 * es) + up(Hh * Wh * 4 * es);               // x4, half4
+  b += 3 * up((Hh + 2) * (Wh + 2) * 2 * G * es);            // g, t1, t2
+  b += up(P * 192 * es);                                    // patches of the 7x7 stems
+  b += 2 * up((size_t)(H + 6) * (W + 6) * ngf * es);        // l1, l2
+  b += up((size_t)(H + 2) * (W + 2) * G * es);              // zero-inserted canvas
+  b += up(P * 8 * es);                                      // y8
+  return b + 4096;
 }
 
 // page_dev u8 BGR [h][w][3] -> fake_rgb_dev u8 RGB [H][W][3] on the padded canvas (mhip_overlay_padded_shape); raw_dev (optional)

@@ -317,11 +317,10 @@ static int conv_c3_t(mhip_ctx* ctx, const void* in, const float* wt, const float
                      int stride, int pad, int refl) {
   constexpr int CS = COUT >= 16 ? COUT : 4, GROUPS = COUT >= 16 ? 4 : 1;
   const size_t lds = (size_t)K * K * 3 * CS * 4;
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr;
+  std::call_once(attr, [&] {
     (void)hipFuncSetAttribute((const void*)ov_conv_c3_kernel<T, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 147 * 256 * 4);
-    attr = true;
-  }
+  });
   return run(ctx, "ov_conv_c3", [&] {
     hipLaunchKernelGGL((ov_conv_c3_kernel<T, COUT>), dim3(blocks((size_t)Ho * Wo, 256 / GROUPS)), dim3(256), lds, ctx->stream, (const T*)in,
                        wt, bias, (T*)out, H, W, Ho, Wo, K, stride, pad, refl);

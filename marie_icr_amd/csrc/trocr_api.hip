@@ -30,6 +30,7 @@ struct mhip_trocr {
   void* frag_scratch = nullptr;
   size_t frag_scratch_bytes = 0;
   bool absorb = false;       // encoder-attention with absorbed K / V projections (f16 mode)
+  mhip_gate* decode_gate = nullptr;   // signalled where the decode phase of a generate call starts in the stream
   size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
 };
 
@@ -85,7 +86,11 @@ extern "C" int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_
   a.take("lne_g", D * 4); a.take("lne_b", D * 4);
   for (int l = 0; l < c.dec_layers; ++l) {
     for (const char* n : {"sa_q", "sa_k", "sa_v", "sa_o", "ca_q", "ca_o"}) { a.take(lay(l, n) + "_w", D * D * es); a.take(lay(l, n) + "_b", D * 4); }
-    for (const char* n : {"ca_k", "ca_v"}) { a.take(lay(l, n) + "_w", D * E * es); a.take(lay(l, n) + "_b", D * 4); }
+    // absorbed encoder-attention: W_k lives only as ca_kt and b_k drops out of the soft-max — no ca_k slots in the arena
+    for (const char* n : {"ca_k", "ca_v"}) {
+      if (m->absorb && !strcmp(n, "ca_k")) continue;
+      a.take(lay(l, n) + "_w", D * E * es); a.take(lay(l, n) + "_b", D * 4);
+    }
     if (m->absorb) a.take(lay(l, "ca_kt"), D * E * 2);     // W_k per head, transposed, x log2(e): [heads][E][64] f16
     a.take(lay(l, "fc1_w"), F * D * es); a.take(lay(l, "fc1_b"), F * 4);
     a.take(lay(l, "fc2_w"), D * F * es); a.take(lay(l, "fc2_b"), D * 4);
@@ -97,7 +102,7 @@ extern "C" int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_
 
 extern "C" int mhip_trocr_destroy(mhip_trocr* m) {
   if (!m) return MHIP_OK;
-  mhip_quiesce();
+  mhip_quiesce(m->ctx);
   mhip_vit_destroy(m->vit);
   m->arena.release();
   if (m->frag_crops) (void)hipFree(m->frag_crops);
@@ -173,6 +178,7 @@ extern "C" int mhip_trocr_finalize(mhip_trocr* m) {
                         {"ca_v", p + "encoder_attn.v_proj", D, E, 1.f}, {"ca_o", p + "encoder_attn.out_proj", D, D, 1.f},
                         {"fc1", p + "fc1", F, D, 1.f}, {"fc2", p + "fc2", D, F, 1.f}};
     for (const Lin& L : lins) {
+      if (m->absorb && !strcmp(L.name, "ca_k")) continue;
       const HostTensor* w = st.find(ctx, L.key + ".weight", {L.out, L.in});
       const HostTensor* b = st.find(ctx, L.key + ".bias", {L.out});
       if (!w || !b) return MHIP_ESTATE;
@@ -209,6 +215,12 @@ extern "C" int mhip_trocr_finalize(mhip_trocr* m) {
   if ((rc = a.upload(ctx))) return rc;
   m->ready = true;
   m->store.t.clear();
+  return MHIP_OK;
+}
+
+extern "C" int mhip_trocr_set_decode_gate(mhip_trocr* m, mhip_gate* gate) {
+  if (!m) return MHIP_EINVAL;
+  m->decode_gate = gate;
   return MHIP_OK;
 }
 
@@ -272,6 +284,9 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
     if ((rc = mhip_gemm(ctx, prec, run.tokens, a.d(lay(l, "ca_k") + "_w"), (long long)n * vg.npad, D, E, nullptr, a.d<float>(lay(l, "ca_k") + "_b"), ck + l * cross_l, ACT_NONE, 0))) return rc;
     if ((rc = mhip_gemm(ctx, prec, run.tokens, a.d(lay(l, "ca_v") + "_w"), (long long)n * vg.npad, D, E, nullptr, a.d<float>(lay(l, "ca_v") + "_b"), cv + l * cross_l, ACT_NONE, 0))) return rc;
   }
+  // the MFMA-bound part of the call is enqueued; what follows is HBM- and latency-bound: whoever waits on the gate (the
+  // detector of the next page batch) runs underneath it
+  if (m->decode_gate && (rc = mhip_gate_signal(m->decode_gate, ctx))) return rc;
   // ---- decoder state ------------------------------------------------------------------------------------------------
   const size_t hist_s = (size_t)M * D * es;                  // one step of one layer
   char* hk = ws.take((size_t)L * (ML + 1) * hist_s);

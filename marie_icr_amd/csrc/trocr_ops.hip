@@ -313,6 +313,7 @@ __global__ __launch_bounds__(CAND_T) void beam_candidates_kernel(CandArgs p) {
         f[e] = (c * EPC + e < p.vocab) ? (float)v[e] : -INFINITY;      // columns past the vocabulary are row padding
         cm = fmaxf(cm, f[e]);
       }
+      if (cm == -INFINITY) continue;       // a chunk of -inf logits adds nothing; (-inf) - (-inf) below would be NaN
       if (cm > m) { sum *= __builtin_amdgcn_exp2f((m - cm) * L2E); m = cm; }     // m = -inf: exp2(-inf) = 0, sum stays 0
 #pragma unroll
       for (int e = 0; e < EPC; ++e) sum += __builtin_amdgcn_exp2f((f[e] - m) * L2E);

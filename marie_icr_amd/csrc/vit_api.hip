@@ -75,7 +75,7 @@ extern "C" int mhip_vit_create(mhip_ctx* ctx, int precision, const mhip_vit_conf
 
 extern "C" int mhip_vit_destroy(mhip_vit* m) {
   if (!m) return MHIP_OK;
-  mhip_quiesce();
+  mhip_quiesce(m->ctx);
   m->arena.release();
   for (auto& t : m->pos_tables) { (void)hipFree(t.dev); if (t.dev16) (void)hipFree(t.dev16); }
   delete m;

@@ -493,11 +493,10 @@ int mhip_launch_attention(mhip_ctx* ctx, int precision, const AttnDesc& d) {
   a.nqb = (d.n_queries + AT_QB - 1) / AT_QB;
   if (ctx->profiling) ctx->prof[MHIP_K_ATTN_FLASH].flops += mhip_attention_flops(d);
   if (precision == MHIP_PREC_F16) {
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [&] {
       (void)hipFuncSetAttribute((const void*)attn_flash_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AT_NSTAGE * AT_STAGE);
-      attr = true;
-    }
+    });
     dim3 grid((unsigned)(a.nqb * d.heads * d.images)), block(AT_THREADS);
     PROF_LAUNCH(ctx, MHIP_K_ATTN_FLASH,
                 hipLaunchKernelGGL(attn_flash_f16_kernel, grid, block, AT_NSTAGE * AT_STAGE, ctx->stream, a));

@@ -96,6 +96,16 @@ class BoxProcessorUlimDit:
         self.cuda = cuda
         self.refinement = refinement
         self.strict_box_segmentation = False
+        if state is None and dit_model is None:
+            # the reference's default: MODEL.WEIGHTS of mask_rcnn_dit_prod.yaml:12 under the model zoo
+            # (ulim_dit_box_processor.py:384-417).  Looked up before a device context exists, so that a missing checkpoint is
+            # the loader's error whatever the machine.
+            from .constants import __model_path__
+
+            models_dir = __model_path__ if models_dir is None else models_dir
+            path = os.path.join(models_dir, "unilm/dit/text_detection/tuned-4000-LARGE-05302024/model_0147999.pth")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"File not found : {path}")
         self.ctx = ctx or (dit_model.ctx if dit_model is not None else Context(device_id))
         if dit_model is not None:            # an already-loaded detector (its weights stay where they are)
             self.model = dit_model
@@ -103,12 +113,8 @@ class BoxProcessorUlimDit:
             self.min_size_test = [self.model.cfg.min_size_test, self.model.cfg.min_size_test]
             return
         if state is None:
-            if models_dir is None:
-                raise ValueError("either `state` or `models_dir` is required")
             import torch
 
-            # mask_rcnn_dit_prod.yaml:12 (MODEL.WEIGHTS, relative to the model zoo root)
-            path = os.path.join(models_dir, "unilm/dit/text_detection/tuned-4000-LARGE-05302024/model_0147999.pth")
             sd = torch.load(path, map_location="cpu", weights_only=True)
             sd = sd.get("model", sd)
             state = {k: (v.numpy() if hasattr(v, "numpy") else np.asarray(v)) for k, v in sd.items()}

@@ -120,14 +120,19 @@ class CraftOcrProcessor(OcrProcessor):
         if not cuda:
             raise MarieHipError("CraftOcrProcessor here is the MI355X path; cuda=False has no implementation")
         self.character = character
+        if state is None:
+            # craft_ocr_processor.py:30,38-42: models_dir defaults to <model zoo>/icr; looked up before a device context exists
+            from .constants import __model_path__
+
+            models_dir = os.path.join(__model_path__, "icr") if models_dir is None else models_dir
+            path = os.path.join(models_dir, "TPS-ResNet-BiLSTM-Attn-case-sensitive-ft", "best_accuracy.pth")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"File not found : {path}")
         self.ctx = ctx or Context(device_id)
         self.batch_size = int(kwargs.get("batch_size", 2048))
         if state is None:
-            if models_dir is None:
-                raise ValueError("either `state` or `models_dir` is required")
             import torch
 
-            path = os.path.join(models_dir, "TPS-ResNet-BiLSTM-Attn-case-sensitive-ft", "best_accuracy.pth")
             sd = torch.load(path, map_location="cpu", weights_only=True)
             state = {k: v.numpy() for k, v in sd.items()}
         prec = {"f16": PREC_F16, "fp16": PREC_F16, "f32": PREC_F32, "fp32": PREC_F32}[precision]

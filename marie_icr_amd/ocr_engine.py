@@ -13,7 +13,9 @@ with 4 px of padding as in :169-184.
 """
 from __future__ import annotations
 
+import contextlib
 import hashlib
+import os
 from copy import deepcopy
 from enum import Enum
 from itertools import chain
@@ -77,10 +79,30 @@ class OcrEngine:
     """reference: marie/ocr/ocr_engine.py:28-433."""
 
     def __init__(self, models_dir: Optional[str] = None, cuda: bool = True, *, box_processor=None, **kwargs) -> None:
-        if box_processor is None:
-            raise ValueError("pass the MI355X box processor explicitly (e.g. marie_icr_amd.craft.BoxProcessorCraft)")
-        self.has_cuda = cuda
-        self.box_processor = box_processor
+        """reference: ocr_engine.py:35-70.  Without a box processor one is built from ``box_segmentation_mode`` (1 = DiT,
+        2 = CRAFT) with the model zoo's default checkpoints; a missing checkpoint is the loader's FileNotFoundError.  The
+        reference ignores ``models_dir`` here (its processors read ``__model_path__``); given explicitly it is handed on."""
+        self.work_dir_icr = "/tmp/icr"
+        has_cuda = cuda
+        if os.environ.get("MARIE_DISABLE_CUDA"):
+            has_cuda = False
+        self.has_cuda = has_cuda
+        if box_processor is not None:
+            self.box_processor = box_processor
+            return
+        box_segmentation_mode = int(kwargs.get("box_segmentation_mode", "1"))
+        if box_segmentation_mode == 1:
+            from .dit_box_processor import BoxProcessorUlimDit
+
+            self.box_processor = BoxProcessorUlimDit(work_dir="/tmp/boxes", models_dir=models_dir, cuda=has_cuda)
+        elif box_segmentation_mode == 2:
+            from .craft import BoxProcessorCraft
+
+            self.box_processor = BoxProcessorCraft(
+                work_dir="/tmp/boxes", models_dir=None if models_dir is None else os.path.join(models_dir, "craft"),
+                cuda=has_cuda)
+        else:
+            raise Exception(f"Unsupported box segmentation mode : {box_segmentation_mode}")
 
     def extract(self, frames, pms_mode: PSMode = PSMode.SPARSE,
                 coordinate_format: CoordinateFormat = CoordinateFormat.XYXY, regions=None, queue_id: str = None,
@@ -158,19 +180,27 @@ class OcrEngine:
         return result
 
     page_batch = 32      # pages per detector / recognizer batch of the batched full-page path
+    first_batch = 8      # pages of the first batch when batches overlap: nothing hides the first detector batch, so it is short
 
     def _fullpage_batched(self, frames, queue_id, checksum, pms_mode, coordinate_format, box_processor, icr_processor):
         """The per-page loop of ocr_engine.py:172-221 with both models batched: ``page_batch`` pages go through the detector
         together (same-size pages share a forward) and their fragments are pooled into one recognizer batch.  A page's result
         is what the per-page loop returns (tests/test_pipeline_gpu.py).  With more than one batch and the two processors on
-        different contexts, the detector of batch k + 1 runs on its own stream and host thread under the recognizer of batch k."""
+        different contexts, the detector of batch k + 1 runs on its own stream and host thread under the recognizer of batch
+        k — under its DECODE phase when the recognizer has one and says where it starts (``decode_gate``, a
+        ``_lib.PhaseGate``): both models are MFMA-bound while the recognizer encodes, so racing them there only stretches
+        both."""
         import queue
         import threading
 
         import torch
 
         B = max(1, int(self.page_batch))
-        chunks = [list(range(s, min(len(frames), s + B))) for s in range(0, len(frames), B)]
+        overlap = len(frames) > 1 and getattr(box_processor, "ctx", None) is not getattr(icr_processor, "ctx", None)
+        head = min(B, max(1, int(self.first_batch))) if overlap and len(frames) > B // 2 else B
+        starts = [0] + list(range(head, len(frames), B))
+        chunks = [list(range(s, min(len(frames), e))) for s, e in zip(starts, starts[1:] + [len(frames)])]
+        overlap = overlap and len(chunks) > 1
 
         def detect(idx):
             return box_processor.extract_bounding_boxes_batch(queue_id, checksum, [frames[i] for i in idx], pms_mode)
@@ -180,39 +210,78 @@ class OcrEngine:
             recs = icr_processor.recognize_pages(queue_id, checksum, pages)
             return [self._finish_page(r, i, f[2], f[4], coordinate_format) for i, f, (r, _) in zip(idx, found, recs)]
 
-        overlap = len(chunks) > 1 and getattr(box_processor, "ctx", None) is not getattr(icr_processor, "ctx", None)
         results: List[Dict] = []
         if not overlap:
             for idx in chunks:
                 results.extend(recognize(idx, detect(idx)))
             return results
         q: "queue.Queue" = queue.Queue(maxsize=2)
-        det_stream = torch.cuda.Stream()
+        stop = threading.Event()
+        gate = getattr(icr_processor, "decode_gate", None)
+        targets: "queue.Queue" = queue.Queue()        # consumer -> producer: the gate signal that opens the next detector batch
+        # processors without a device (the oracle-backed ones of the CPU plumbing tests) overlap as plain host threads
+        on_gpu = torch.cuda.is_available()
+        det_stream = torch.cuda.Stream() if on_gpu else None
+        det_ctx = getattr(box_processor, "ctx", None) if on_gpu else None
+
+        def hand_over(item) -> bool:
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def producer():
             try:
-                with torch.cuda.stream(det_stream):
-                    for idx in chunks:
-                        q.put((idx, detect(idx)))
+                with (torch.cuda.stream(det_stream) if on_gpu else contextlib.nullcontext()):
+                    for k, idx in enumerate(chunks):
+                        if gate is not None and k > 0:
+                            seq = None
+                            while seq is None and not stop.is_set():
+                                try:
+                                    seq = targets.get(timeout=0.1)
+                                except queue.Empty:
+                                    pass
+                            if seq is not None and det_ctx is not None:
+                                det_ctx.set_stream(det_stream.cuda_stream)
+                                gate.wait(det_ctx, seq, timeout_ms=30000)
+                        if stop.is_set() or not hand_over((idx, detect(idx))):
+                            return
             except BaseException as e:              # surfaced on the consumer side
-                q.put(e)
+                hand_over(e)
             finally:
                 # det_stream dies with this call: the detector's context must not keep its handle (a later call sets its own
                 # stream again; a destroy that synchronised the dead handle would abort the process)
-                ctx = getattr(box_processor, "ctx", None)
-                if ctx is not None:
+                if det_ctx is not None:
                     det_stream.synchronize()
-                    ctx.set_stream(None)
+                    det_ctx.set_stream(None)
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
-        for _ in chunks:
-            item = q.get()
-            if isinstance(item, BaseException):
-                th.join()
-                raise item
-            results.extend(recognize(*item))
-        th.join()
+        try:
+            for _ in chunks:
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                if gate is not None:
+                    targets.put(gate.count() + 1)       # the first decode phase of this batch's recognizer call
+                results.extend(recognize(*item))
+        finally:
+            # whatever ended the loop (a recognizer error included): the producer must not stay blocked on the queue or the
+            # gate holding device pages, and its stream must leave the detector's context
+            stop.set()
+            if gate is not None:
+                gate.open(True)
+            while th.is_alive():
+                try:
+                    q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()
+            if gate is not None:
+                gate.open(False)
         return results
 
     def _process_extract_regions(self, frames, queue_id, checksum, pms_mode, regions, box_processor, icr_processor,
@@ -277,9 +346,14 @@ class MarieHipOcrEngine(OcrEngine):
 
     def __init__(self, models_dir: Optional[str] = None, cuda: bool = True, *, box_processor=None,
                  default_ocr_processor=None, **kwargs) -> None:
+        """reference: default_ocr_engine.py:32-58 — the recognizer defaults to ``TrOcrProcessor`` on the zoo's checkpoint."""
         super().__init__(models_dir=models_dir, cuda=cuda, box_processor=box_processor, **kwargs)
         if default_ocr_processor is None:
-            raise ValueError("pass the MI355X recognizer explicitly (e.g. marie_icr_amd.crnn.CrnnOcrProcessor)")
+            from .trocr import TrOcrProcessor
+
+            default_ocr_processor = TrOcrProcessor(
+                work_dir=self.work_dir_icr, cuda=self.has_cuda,
+                model_name_or_path=None if models_dir is None else os.path.join(models_dir, "trocr", "trocr-large-printed.pt"))
         self.ocr_processor = default_ocr_processor
 
     def extract(self, frames, pms_mode: PSMode = PSMode.SPARSE,
@@ -287,6 +361,24 @@ class MarieHipOcrEngine(OcrEngine):
                 **kwargs: Any) -> List[Dict]:
         return self.process_single(self.box_processor, self.ocr_processor, frames, pms_mode, coordinate_format,
                                    regions, queue_id, **kwargs)
+
+
+class MockOcrEngine(OcrEngine):
+    """reference: marie/ocr/mock_ocr_engine.py:17-53 — returns the results a previous run stored under
+    ``/tmp/generators/<md5 of the frames>/results/results.json``; raises when there are none.  (The reference's constructor
+    drops ``box_processor`` on its way to the base class and so builds a default detector it never uses; this one does not.)"""
+
+    def __init__(self, models_dir: Optional[str] = None, cuda: bool = True, *, box_processor=None, **kwargs) -> None:
+        self.has_cuda = cuda
+        self.box_processor = box_processor
+
+    def extract(self, frames, pms_mode: PSMode = PSMode.SPARSE,
+                coordinate_format: CoordinateFormat = CoordinateFormat.XYWH, regions=None, queue_id: str = None, **kwargs):
+        import json
+
+        path = os.path.join("/tmp/generators", hash_frames_fast(frames), "results", "results.json")
+        with open(path, "r", encoding="utf-8") as f:
+            return json.load(f)
 
 
 class _MemoBoxProcessor:
@@ -402,12 +494,22 @@ class MarieHipVotingOcrEngine(OcrEngine):
         from collections import OrderedDict
 
         self.processors = OrderedDict()
-        if default_ocr_processor is not None:
-            self.processors["default"] = {"enabled": True, "default": True, "processor": default_ocr_processor}
+        if default_ocr_processor is None:
+            # voting_ocr_engine.py:49-64: "default" = TrOcrProcessor, "craft" = CraftOcrProcessor on the zoo's checkpoints
+            from .trocr import TrOcrProcessor
+
+            default_ocr_processor = TrOcrProcessor(
+                work_dir=self.work_dir_icr, cuda=self.has_cuda,
+                model_name_or_path=None if models_dir is None else os.path.join(models_dir, "trocr", "trocr-large-printed.pt"))
+            if processors is None:
+                from .icr import CraftOcrProcessor
+
+                processors = {"craft": CraftOcrProcessor(
+                    work_dir=self.work_dir_icr, cuda=self.has_cuda,
+                    models_dir=None if models_dir is None else os.path.join(models_dir, "icr"))}
+        self.processors["default"] = {"enabled": True, "default": True, "processor": default_ocr_processor}
         for name, proc in (processors or {}).items():
             self.processors[name] = proc if isinstance(proc, dict) else {"enabled": True, "processor": proc}
-        if not self.processors:
-            raise ValueError("pass the MI355X recognizers explicitly (default_ocr_processor=..., processors={...})")
         first = next(iter(self.processors.values()))
         first.setdefault("default", True)
 

@@ -93,8 +93,16 @@ class TrocrModel:
               "mhip_trocr_generate_fragments")
         return self._unpack(tokens, lengths, scores)
 
+    def decode_gate(self):
+        """The model's phase gate (created on first use): signalled in every generate call where decoding starts."""
+        if getattr(self, "_gate", None) is None:
+            self._gate = self.ctx.make_gate()
+            check(self.ctx.h, self.lib.mhip_trocr_set_decode_gate(self.h, self._gate.h), "mhip_trocr_set_decode_gate")
+        return self._gate
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.mhip_trocr_set_decode_gate(self.h, None)
             self.lib.mhip_trocr_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -190,16 +198,28 @@ class TrOcrProcessor(OcrProcessor):
         super().__init__(work_dir, cuda)
         if not cuda:
             raise MarieHipError("TrOcrProcessor here is the MI355X path; cuda=False has no implementation")
-        self.ctx = ctx or (trocr_model.ctx if trocr_model is not None else Context(device_id))
-        cfg = trocr_model.cfg if trocr_model is not None else (config or default_config(self.ctx.lib, model))
         if state is None and trocr_model is None:
-            if model_name_or_path is None or not os.path.exists(model_name_or_path):
-                raise FileNotFoundError(f"File not found : {model_name_or_path}")
+            # trocr_ocr_processor.py:199-217: <model zoo>/trocr/trocr-large-printed.pt unless a path is given; a missing file
+            # is FileNotFoundError.  Resolved (and read) before a device context exists.
+            from .constants import __model_path__
+
+            model_path = os.path.join(__model_path__, "trocr", "trocr-large-printed.pt")
+            if model_name_or_path:
+                model_path = model_name_or_path
+            if not os.path.exists(model_path):
+                raise FileNotFoundError(f"File not found : {model_path}")
             import torch
 
-            ck = torch.load(model_name_or_path, map_location="cpu", weights_only=True)
+            ck = torch.load(model_path, map_location="cpu", weights_only=True)
             sd = ck.get("model", ck)
             state = {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}
+            if config is None:
+                # the checkpoint says which architecture it is (trocr_models.py:423-470: base = DeiT 768, large = 1024)
+                pe = state.get("encoder.deit.pos_embed")
+                if pe is not None:
+                    model = "large" if pe.shape[-1] == 1024 else "base"
+        self.ctx = ctx or (trocr_model.ctx if trocr_model is not None else Context(device_id))
+        cfg = trocr_model.cfg if trocr_model is not None else (config or default_config(self.ctx.lib, model))
         if encoder_json and not dict_path:
             # the dictionary's symbols ARE the GPT-2 BPE ids; decoding dictionary indices as BPE ids would be silently wrong
             raise ValueError("encoder_json needs dict_path: GPT-2 BPE ids are the fairseq dictionary's symbols, not its indices")
@@ -210,6 +230,9 @@ class TrOcrProcessor(OcrProcessor):
         prec = {"f16": PREC_F16, "fp16": PREC_F16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
         self.model = trocr_model if trocr_model is not None else TrocrModel(self.ctx, state, cfg, prec)
         self.batch_size = int(batch_size)
+        # where the decode phase of a generate call starts in this recognizer's stream (the engine runs the next page batch's
+        # detector under it, ocr_engine.OcrEngine._fullpage_batched)
+        self.decode_gate = self.model.decode_gate()
 
     def is_available(self) -> bool:
         return self.model is not None

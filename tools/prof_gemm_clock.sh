@@ -1,4 +1,4 @@
-# Effective clock and MFMA-busy share of conv_igemm<256> on the ViT GEMM shapes: rocprofv3 --pmc passes over tools/ubench/gb_prod
+# Effective clock and MFMA-busy share of conv_igemm<256> on the ViT GEMM shapes: rocprofv3 --pmc passes over tools/ubenc./bin/gb_prod
 # (counters only with --kernel-trace, one group per pass).  Build the binary here first: (cd tools/ubench && ./build_gb.sh prod).  GRBM_GUI_ACTIVE / 8 / wall = clock; SQ_VALU_MFMA_BUSY_CYCLES summed over
 # the 1024 SIMDs / (1024 x GRBM_GUI_ACTIVE / 8) = share of cycles the matrix cores are busy.
 cd /tmp && export TMPDIR=/tmp
@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT/tools/ubench
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof
 for c in GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES; do
   rm -rf /tmp/gclk_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/gclk_$c -- ./gb_prod 1477120 3 > /tmp/gclk_$c.out 2>/tmp/gclk_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/gclk_$c -- ./bin/gb_prod 1477120 3 > /tmp/gclk_$c.out 2>/tmp/gclk_$c.err
   echo "$c rc=$?"
   cp $(find /tmp/gclk_$c -name "*counter_collection.csv" | head -1) $GRAFT_REPO_ROOT/gpurun_out/prof/gclk_$c.csv
   cp $(find /tmp/gclk_$c -name "*kernel_trace.csv" | head -1) $GRAFT_REPO_ROOT/gpurun_out/prof/gclk_trace_$c.csv

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT/tools/ubench
 for v in "$@"; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pg_${v}_$c
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pg_${v}_$c -- ./gb_$v 369280 2 > /tmp/pg_${v}_$c.out 2>/dev/null
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pg_${v}_$c -- ./bin/gb_$v 369280 2 > /tmp/pg_${v}_$c.out 2>/dev/null
   done
   python3 - $v <<'PY'
 import csv, sys, glob, collections

@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT/tools/ubench
 for v in "$@"; do
   echo "== $v"
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -- ./cab_$v ${CAB_ARGS:-1280 3 16 577 768 20} 2>/dev/null | grep -E "us per|checksum"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -- ./bin/cab_$v ${CAB_ARGS:-1280 3 16 577 768 20} 2>/dev/null | grep -E "us per|checksum"
   f=$(find /tmp/prof_$v -name "*kernel_stats.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys
