@@ -315,11 +315,16 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
     dims = ((tcfg.enc_dim, tcfg.enc_depth, tcfg.enc_heads), (tcfg.dec_dim, tcfg.dec_layers, tcfg.dec_heads, tcfg.dec_ffn),
             tcfg.vocab)
     need_state = rank == 0
+    pg_info = None
     dit_state = make_dit_state(0, args.model) if need_state else None
     trocr_state = make_trocr_state(0, dims[0], dims[1], dims[2], tcfg.max_positions) if need_state else None
     det = DitModel(ctxs[0], dit_state, model=args.model, precision=prec)
     rec = TrocrModel(ctxs[1], trocr_state, tcfg, prec)
-    if world > 1:      # rank 0 packed the weights; everyone else receives the packed arenas over RCCL / xGMI
+    # the recognizer says where its decode phase starts in its stream; the detector's stream waits there (--no-phase-align:
+    # the two streams race from the start of the step, the round-2 behaviour)
+    gate = None if args.no_phase_align else rec.decode_gate()
+    if dist is not None:   # rank 0 packed the weights; everyone else receives the packed arenas over RCCL / xGMI (a launcher
+        # with one rank goes through the same collectives: the RCCL path is exercised on a one-GPU box too)
         for m, c, s_ in ((det, ctxs[0], streams[0]), (rec, ctxs[1], streams[1])):
             if rank != 0:
                 m.alloc_arena()
@@ -329,6 +334,7 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
                 dist.all_gather_object(sums, arenas_checksum(m, c))
                 if len(set(sums)) != 1:
                     raise SystemExit(f"rank {rank}: weight arenas differ across ranks after the broadcast: {sums}")
+        pg_info = {"backend": dist.get_backend(), "world": world, "arena_checksums_equal": True}
     n_pool = min(P, 4)
     host_pages = np.stack([make_page_bgr(1000 + rank * 97 + i, PAGE_H, PAGE_W, n_lines=LINES_PER_PAGE) for i in range(n_pool)])
     pages = torch.from_numpy(host_pages[np.arange(P) % n_pool]).cuda()     # [P][H][W][3] in HBM
@@ -351,10 +357,15 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
     # what a step works on: device address of a packed page buffer, the slots of the step's pages in it, their crop windows
     cur = {"base": pages.data_ptr(), "slots": list(range(P)), "descs": make_descs(range(P))}
 
+    gate_seq = [None]          # signal this step's detector waits for (None: not gated)
+
     def detect_all():
         nb = 0
         per_page = []
         slots = cur["slots"]
+        if gate is not None and gate_seq[0] is not None:
+            gate.wait(ctxs[0], gate_seq[0], timeout_ms=60000)
+            gate_seq[0] += 1
         for pz in range(det_passes[0]):
             for s0 in range(0, len(slots), DB):
                 ptrs = [cur["base"] + sl * page_bytes for sl in slots[s0:s0 + DB]]
@@ -380,11 +391,16 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
         def loop(fn):
             for _ in range(k):
                 fn()
+        # step j's detector starts where step j's recognizer begins to decode: signal number (count now) + j + 1
+        gate_seq[0] = gate.count() + 1 if gate is not None else None
         ths = [threading.Thread(target=loop, args=(f,)) for f in (detect_all, recognize_all)]
         for th in ths:
             th.start()
-        for th in ths:
-            th.join()
+        try:
+            for th in ths:
+                th.join()
+        finally:
+            gate_seq[0] = None
 
     def fence():
         torch.cuda.synchronize()
@@ -470,7 +486,7 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
 
     # ---- BASELINE configs[3]: a fixed stream of pages sharded over the ranks, results gathered in page order -------------
     stream = None
-    total = args.stream_pages if args.stream_pages >= 0 else (2048 if world > 1 else 0)
+    total = args.stream_pages if args.stream_pages >= 0 else (2048 if world > 1 else 2 * P)
     if total > 0:
         mine = shard_indices(total, rank, world)          # rank r owns pages r, r + world, ...
         # page i of the stream = seeded page i % 4, the same on every rank (so the gathered result does not depend on N)
@@ -538,7 +554,8 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
                         f"16-bit mode of this build (configs[2] says bf16: same width; the reference's GPU path is .half())"
                         + ("; detector and recognizer run one after the other (--serial)" if args.serial else ""),
             "pages_per_gpu_per_step": P, "crops_per_page": LINES_PER_PAGE, "detector_boxes_per_page": boxes_pp,
-            "parallelism": f"dp{world} (independent pages); detector and recognizer on two streams per GPU",
+            "parallelism": f"dp{world} (independent pages); detector and recognizer on two streams per GPU, the detector "
+                           + ("racing the recognizer" if args.no_phase_align else "started where the recognizer begins to decode"),
         },
     }
     if prof is not None:
@@ -579,6 +596,8 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
         out["kernel_ms_over_wall_ms"] = sum(agg.values()) / (1e3 * dt / args.steps)
         out.update(alone_ms)
     out.update(extra)
+    if pg_info is not None:
+        out["process_group"] = pg_info
     if pcie is not None:
         out["pcie_inclusive"] = pcie
     if stream is not None:
@@ -635,12 +654,17 @@ def run_mixed_dpi(args, torch, dist, rank, world, det, rec, ctxs, streams, fence
                 n += 1
         return ids, buckets, descs, n
 
+    gate = None if args.no_phase_align else rec.decode_gate()
+
     def process(c):
         ids, buckets, descs, n = chunk_inputs(c)
         res = {}
+        seq = gate.count() + 1 if gate is not None else None     # this chunk's recognizer call: where its decoding starts
 
         def detect():
             counts = {}
+            if gate is not None:
+                gate.wait(ctxs[0], seq, timeout_ms=60000)
             for k, ptrs in buckets.items():
                 h, w = MIXED_DPI_SIZES[k]
                 out = []
@@ -760,6 +784,8 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
         return bp
 
     tp = TrOcrProcessor(trocr_model=rec, batch_size=min(P, 32) * LINES_PER_PAGE)
+    if args.no_phase_align:
+        tp.decode_gate = None
     out = {}
     for name, fixed, refine, n_pages in (("fixed_lines", True, False, P), ("detector_driven", False, False, min(P, 8)),
                                          ("detector_driven_refinement", False, True, min(P, 8))):
@@ -838,9 +864,12 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="dit_trocr: detector and recognizer one after the other instead of on two streams (what "
                          "roofline.isolated measures; for rocprofv3 runs of the isolated kernels)")
+    ap.add_argument("--no-phase-align", action="store_true",
+                    help="dit_trocr: let the detector and the recognizer streams race from the start of a step instead of "
+                         "starting the detector where the recognizer begins to decode")
     ap.add_argument("--stream-pages", type=int, default=-1,
                     help="dit_trocr, BASELINE configs[3]: also time a fixed stream of this many pages sharded over the ranks "
-                         "with the results gathered in page order (default: 2048 when N > 1, off at N = 1; 0 = off)")
+                         "with the results gathered in page order (default: 2048 when N > 1, two steps' worth at N = 1; 0 = off)")
     ap.add_argument("--mixed-pages", type=int, default=48,
                     help="dit_trocr, BASELINE configs[4]: pages per GPU of the mixed-DPI stream leg (multiple of 24)")
     ap.add_argument("--no-mixed-dpi", action="store_true")
@@ -886,7 +915,9 @@ def main():
         raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:
+        # under a launcher — `python -m torch.distributed.run --nproc-per-node=1 bench.py` included — the process group is
+        # real: weights broadcast, checksums gathered, timings reduced and the work queue kept in the store, also with one rank
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -398,6 +398,12 @@ int mhip_trocr_generate_host(mhip_trocr* m, const uint8_t* crops_host, int n, in
 /* fragments of any size (3 channels) inside one device buffer -> Pillow bicubic to img x img -> generate                    */
 int mhip_trocr_generate_fragments(mhip_trocr* m, const uint8_t* base_dev, const mhip_crop_desc* descs_host, int n,
                                   int swap_rb, int32_t* tokens_out, int32_t* lengths_out, float* scores_out);
+/* mhip_trocr_generate_host plus the candidate list of every beam-search step as the generator saw it (BeamSearch.step's
+ * top 2*beam of cumulative score, generator.py:208-223): trace_* are host arrays [max_len + 1][n][2 * beam] (scores, token ids,
+ * source beams), *steps_out the number of steps that ran.  For parity tests: the oracle's search is walked beside it. */
+int mhip_trocr_generate_trace_host(mhip_trocr* m, const uint8_t* crops_host, int n, int swap_rb, int32_t* tokens_out,
+                                   int32_t* lengths_out, float* scores_out, float* trace_scores, int32_t* trace_tokens,
+                                   int32_t* trace_beams, int* steps_out);
 /* The decoder's encoder-attention stage alone (one layer, one step) on host inputs, through the f16 kernels that attend over
  * the encoder tokens themselves (key / value projections absorbed: cross_attn.hip).  replaces: fairseq MultiheadAttention
  * (encoder_attn) as TextRecognitionGenerator drives it, marie/models/unilm/trocr/generator.py:127-362.  q [crops*beam][heads*64]

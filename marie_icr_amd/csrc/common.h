@@ -317,6 +317,32 @@ struct BeamCandDesc {
 };
 int mhip_launch_beam_candidates(mhip_ctx* ctx, const BeamCandDesc& d);
 int mhip_launch_ancestry(mhip_ctx* ctx, const int* anc_old, int* anc_new, const int* parent, int rows, int ld, int step);
+// Generator bookkeeping of one beam-search step on the device (TextRecognitionGenerator._generate, generator.py:208-362:
+// finalize_hypos over the eos candidates among the first `beam`, the `beam` best live candidates become the next rows).
+// One thread per crop; finished crops keep their rows (no batch compaction).  All arrays live in HBM.
+struct BeamState {
+  int bsz = 0, beam = 1, max_len = 0, pad = 1, eos = 2;
+  const float* cand_scores = nullptr;   // [bsz][2*beam] (mhip_launch_beam_candidates)
+  const int* cand_tokens = nullptr;
+  const int* cand_beams = nullptr;
+  int* tokens[2] = {nullptr, nullptr};  // [bsz*beam][max_len + 2] hypothesis tokens incl. the leading eos; read [cur], written [cur^1]
+  int* last_tok = nullptr;              // [bsz*beam] token every row feeds to the next step
+  int* parent = nullptr;                // [bsz*beam] row of the previous step a row continues
+  float* cum = nullptr;                 // [bsz*beam] cumulative log-probability of a row
+  unsigned char* ignore = nullptr;      // [bsz*beam] cands_to_ignore
+  unsigned char* finished = nullptr;    // [bsz]
+  int* fin_count = nullptr;             // [bsz] finalized hypotheses so far
+  int* fin_tokens = nullptr;            // [bsz][beam][max_len + 1]
+  int* fin_len = nullptr;               // [bsz][beam]
+  float* fin_score = nullptr;           // [bsz][beam] normalised scores, in finalisation order
+  int* remaining = nullptr;             // [1] crops not finished yet
+};
+size_t mhip_beam_state_bytes(int bsz, int beam, int max_len);
+int mhip_beam_state_carve(void* base, int bsz, int beam, int max_len, int pad, int eos, BeamState* st);   // pointers into `base`
+int mhip_launch_beam_init(mhip_ctx* ctx, const BeamState& st, int* anc0, int anc_ld);
+int mhip_launch_beam_select(mhip_ctx* ctx, const BeamState& st, int cur, int step);
+// best hypothesis per crop -> tokens_out [bsz][max_len + 1] (padded), lengths_out [bsz], scores_out [bsz] (device arrays)
+int mhip_launch_beam_best(mhip_ctx* ctx, const BeamState& st, int* tokens_out, int* lengths_out, float* scores_out);
 size_t mhip_pil_resize_fragments_scratch(const mhip_crop_desc* descs, int n, int dh, int dw, int filter);
 int mhip_pil_resize_fragments(mhip_ctx* ctx, const uint8_t* base_dev, const mhip_crop_desc* descs, int n, uint8_t* dst, int dh,
                               int dw, int filter, void* scratch, size_t scratch_bytes);

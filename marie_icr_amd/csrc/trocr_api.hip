@@ -31,6 +31,9 @@ struct mhip_trocr {
   size_t frag_scratch_bytes = 0;
   bool absorb = false;       // encoder-attention with absorbed K / V projections (f16 mode)
   mhip_gate* decode_gate = nullptr;   // signalled where the decode phase of a generate call starts in the stream
+  // "crops not finished yet" after every step, copied to pinned memory; the host reads it two steps late (never drains the stream)
+  int* h_remaining = nullptr;
+  hipEvent_t rem_ev[2] = {nullptr, nullptr};
   size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
 };
 
@@ -96,6 +99,12 @@ extern "C" int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_
     a.take(lay(l, "fc2_w"), D * F * es); a.take(lay(l, "fc2_b"), D * 4);
     for (const char* n : {"sa_ln", "ca_ln", "fin_ln"}) { a.take(lay(l, n) + "_g", D * 4); a.take(lay(l, n) + "_b", D * 4); }
   }
+  hipError_t he = hipHostMalloc((void**)&m->h_remaining, (size_t)(c.max_positions + 2) * sizeof(int));
+  for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&m->rem_ev[i], hipEventDisableTiming);
+  if (he != hipSuccess) {
+    mhip_trocr_destroy(m);
+    return mhip_fail(ctx, MHIP_EHIP, "trocr: pinned step counter: %s", hipGetErrorString(he));
+  }
   *out = m;
   return MHIP_OK;
 }
@@ -103,6 +112,9 @@ extern "C" int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_
 extern "C" int mhip_trocr_destroy(mhip_trocr* m) {
   if (!m) return MHIP_OK;
   mhip_quiesce(m->ctx);
+  if (m->h_remaining) (void)hipHostFree(m->h_remaining);
+  for (auto e : m->rem_ev)
+    if (e) (void)hipEventDestroy(e);
   mhip_vit_destroy(m->vit);
   m->arena.release();
   if (m->frag_crops) (void)hipFree(m->frag_crops);
@@ -239,7 +251,8 @@ static size_t trocr_ws_bytes(const mhip_trocr* m, int n) {
   else b += 2 * (size_t)c.dec_layers * n * vg.npad * D * es;          // cross K / V
   b += 2 * (size_t)c.dec_layers * (ML + 1) * M * D * es;              // self K / V history
   b += M * D * 4 + 3 * M * D * es + M * c.dec_ffn * es + M * ldv * 4; // x, xt, q, ao, hidden, logits
-  b += 2 * M * (ML + 2) * 4 + 4 * M * 4 + (size_t)n * 2 * c.beam * 12 + (size_t)vg.n_tok * c.enc_dim * 4 + (size_t)c.vocab * 4 + 4096;
+  b += 2 * M * (ML + 2) * 4 + (size_t)n * 2 * c.beam * 12 + (size_t)vg.n_tok * c.enc_dim * 4 + (size_t)c.vocab * 4 + 4096;
+  b += mhip_beam_state_bytes(n, c.beam, (int)ML) + (size_t)n * (ML + 3) * 4 + 1024;   // generator state + device copies of the outputs
   return b + (1 << 16);
 }
 
@@ -247,8 +260,16 @@ extern "C" size_t mhip_trocr_workspace_bytes(mhip_trocr* m, int n) { return (m &
 
 // crops_dev: n images u8 [img][img][3].  tokens_out [n][max_len + 1] (the hypothesis without the leading eos, eos included,
 // padded with `pad`), lengths_out [n], scores_out [n] (length-normalised log-probability of the best hypothesis).
+struct TrocrTrace {          // host arrays [max_len + 1][n][2 * beam], filled for the steps that ran
+  float* scores;
+  int32_t* tokens;
+  int32_t* beams;
+  int steps;
+};
+
 static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int swap_rb, int32_t* tokens_out,
-                          int32_t* lengths_out, float* scores_out, float* enc_tokens_host, float* step0_logits_host) {
+                          int32_t* lengths_out, float* scores_out, float* enc_tokens_host, float* step0_logits_host,
+                          TrocrTrace* trace = nullptr) {
   mhip_ctx* ctx = m->ctx;
   if (!m->ready) return mhip_fail(ctx, MHIP_ESTATE, "trocr: weights not finalized");
   if (n < 1) return mhip_fail(ctx, MHIP_EINVAL, "trocr: empty batch");
@@ -299,42 +320,32 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
   char* logits = ws.take((size_t)M * ldv * 4);      // element type T: f16 logits in the f16 mode, fp32 in the parity mode
   const int anc_ld = ML + 2;
   int* anc[2] = {ws.take<int>((size_t)M * anc_ld * 4), ws.take<int>((size_t)M * anc_ld * 4)};
-  int* d_tok = ws.take<int>((size_t)M * 4);
-  int* d_parent = ws.take<int>((size_t)M * 4);
-  float* d_cum = ws.take<float>((size_t)M * 4);
   float* d_cs = ws.take<float>((size_t)n * K2 * 4);
   int* d_ct = ws.take<int>((size_t)n * K2 * 4);
   int* d_cb = ws.take<int>((size_t)n * K2 * 4);
-
-  // host bookkeeping (TextRecognitionGenerator._generate without batch compaction: finished crops keep their rows)
-  std::vector<int> tokens((size_t)M * (ML + 2), c.pad), tokens_new(tokens.size());
-  std::vector<float> scores((size_t)M * (ML + 1), 0.f), scores_new(scores.size());
-  for (int r = 0; r < M; ++r) tokens[(size_t)r * (ML + 2)] = c.eos;
-  struct Hypo { float score; std::vector<int> toks; };
-  std::vector<std::vector<Hypo>> finalized(n);
-  std::vector<char> finished(n, 0), ignore((size_t)n * beam, 0);
-  int remaining = n;
-  std::vector<int> h_tok(M), h_parent(M), h_ct((size_t)n * K2), h_cb((size_t)n * K2);
-  std::vector<float> h_cum(M, 0.f), h_cs((size_t)n * K2);
-  for (int r = 0; r < M; ++r) { h_tok[r] = c.eos; h_parent[r] = r; }
-  {  // ancestry of step 0: every hypothesis reads its own slot
-    std::vector<int> a0((size_t)M * anc_ld, 0);
-    for (int r = 0; r < M; ++r) a0[(size_t)r * anc_ld] = r;
-    MHIP_HIP(ctx, hipMemcpyAsync(anc[0], a0.data(), a0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  int cur = 0;
+  // generator state (TextRecognitionGenerator._generate without batch compaction: finished crops keep their rows), all in HBM
+  BeamState bs;
+  if ((rc = mhip_beam_state_carve(ws.take(mhip_beam_state_bytes(n, beam, ML)), n, beam, ML, c.pad, c.eos, &bs))) return rc;
+  bs.cand_scores = d_cs; bs.cand_tokens = d_ct; bs.cand_beams = d_cb;
+  int* d_out_tok = ws.take<int>((size_t)n * (ML + 1) * 4);
+  int* d_out_len = ws.take<int>((size_t)n * 4);
+  float* d_out_score = ws.take<float>((size_t)n * 4);
+  if ((rc = mhip_launch_beam_init(ctx, bs, anc[0], anc_ld))) return rc;
+  int cur = 0, tcur = 0;
   for (int step = 0; step <= ML; ++step) {
-    MHIP_HIP(ctx, hipMemcpyAsync(d_tok, h_tok.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
-    MHIP_HIP(ctx, hipMemcpyAsync(d_cum, h_cum.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (step >= 2) {
+      // the counter of two steps ago: the stream still holds step - 1 while this one is enqueued, so the device never waits for
+      // the host; when every crop has finished, one step too many has been enqueued — finished crops ignore it
+      MHIP_HIP(ctx, hipEventSynchronize(m->rem_ev[step & 1]));
+      if (m->h_remaining[step - 2] == 0) break;
+    }
     if (step > 0) {
-      MHIP_HIP(ctx, hipMemcpyAsync(d_parent, h_parent.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
-      if ((rc = mhip_launch_ancestry(ctx, anc[cur], anc[cur ^ 1], d_parent, M, anc_ld, step - 1))) return rc;
+      if ((rc = mhip_launch_ancestry(ctx, anc[cur], anc[cur ^ 1], bs.parent, M, anc_ld, step - 1))) return rc;
       cur ^= 1;
     }
     // LearnedPositionalEmbedding, incremental: position = padding_idx + (step + 1)
     const float* pos_row = a.d<float>("pos") + (size_t)(c.pad + step + 1) * D;
-    if ((rc = mhip_launch_embed_step(ctx, prec, d_tok, a.d("emb"), pos_row, c.embed_scale, a.d<float>("lne_g"), a.d<float>("lne_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
+    if ((rc = mhip_launch_embed_step(ctx, prec, bs.last_tok, a.d("emb"), pos_row, c.embed_scale, a.d<float>("lne_g"), a.d<float>("lne_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
     for (int l = 0; l < L; ++l) {
       char* kl = hk + ((size_t)l * (ML + 1)) * hist_s;
       char* vl = hv + ((size_t)l * (ML + 1)) * hist_s;
@@ -379,87 +390,29 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
       }
     }
     BeamCandDesc bc;
-    bc.logits = logits; bc.logits_f16 = prec == MHIP_PREC_F16; bc.ld = ldv; bc.vocab = c.vocab; bc.beam = beam; bc.bsz = n; bc.cum = d_cum; bc.step = step;
+    bc.logits = logits; bc.logits_f16 = prec == MHIP_PREC_F16; bc.ld = ldv; bc.vocab = c.vocab; bc.beam = beam; bc.bsz = n; bc.cum = bs.cum; bc.step = step;
     bc.max_len = ML; bc.min_len = c.min_len; bc.pad = c.pad; bc.eos = c.eos;
     bc.cand_scores = d_cs; bc.cand_tokens = d_ct; bc.cand_beams = d_cb;
     if ((rc = mhip_launch_beam_candidates(ctx, bc))) return rc;
-    MHIP_HIP(ctx, hipMemcpyAsync(h_cs.data(), d_cs, (size_t)n * K2 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MHIP_HIP(ctx, hipMemcpyAsync(h_ct.data(), d_ct, (size_t)n * K2 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MHIP_HIP(ctx, hipMemcpyAsync(h_cb.data(), d_cb, (size_t)n * K2 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // ---- generator bookkeeping for this step ----------------------------------------------------------------------
-    tokens_new = tokens;
-    scores_new = scores;
-    for (int s = 0; s < n; ++s) {
-      if (finished[s]) {
-        for (int b = 0; b < beam; ++b) { h_parent[s * beam + b] = s * beam + b; h_tok[s * beam + b] = c.eos; }
-        continue;
-      }
-      const float* cs = &h_cs[(size_t)s * K2];
-      const int* ct = &h_ct[(size_t)s * K2];
-      const int* cb = &h_cb[(size_t)s * K2];
-      bool eos_mask[8];
-      for (int j = 0; j < K2; ++j) eos_mask[j] = ct[j] == c.eos && cs[j] != -INFINITY;
-      for (int j = 0; j < beam; ++j)
-        if (ignore[(size_t)s * beam + j]) eos_mask[j] = false;
-      // finalize_hypos: eos candidates among the first `beam`
-      for (int j = 0; j < beam; ++j) {
-        if (!eos_mask[j]) continue;
-        const int src = s * beam + cb[j];
-        if ((int)finalized[s].size() < beam) {
-          Hypo h;
-          h.toks.assign(tokens.begin() + (size_t)src * (ML + 2) + 1, tokens.begin() + (size_t)src * (ML + 2) + 1 + step);
-          h.toks.push_back(c.eos);
-          h.score = cs[j] / (float)(step + 1);          // normalize_scores, len_penalty 1
-          finalized[s].push_back(std::move(h));
-        }
-      }
-      if ((int)finalized[s].size() == beam || step == ML) {
-        if (!finalized[s].empty() || step == ML) {
-          finished[s] = 1;
-          --remaining;
-          for (int b = 0; b < beam; ++b) { h_parent[s * beam + b] = s * beam + b; h_tok[s * beam + b] = c.eos; }
-          continue;
-        }
-      }
-      // active hypotheses: the `beam` best candidates that are not finished ones
-      for (int j = 0; j < beam; ++j) eos_mask[j] = eos_mask[j] || ignore[(size_t)s * beam + j];
-      int order[8], nact = 0;
-      for (int j = 0; j < K2 && nact < beam; ++j)
-        if (!eos_mask[j]) order[nact++] = j;
-      int nign = 0;
-      for (int j = 0; j < K2 && nact + nign < beam; ++j)
-        if (eos_mask[j]) order[nact + nign++] = j;      // fewer than `beam` live candidates: the rest are ignored slots
-      for (int b = 0; b < beam; ++b) {
-        const int j = order[b], row = s * beam + b, src = s * beam + cb[j];
-        ignore[(size_t)s * beam + b] = b >= nact;
-        std::copy(tokens.begin() + (size_t)src * (ML + 2), tokens.begin() + (size_t)src * (ML + 2) + step + 1, tokens_new.begin() + (size_t)row * (ML + 2));
-        tokens_new[(size_t)row * (ML + 2) + step + 1] = ct[j];
-        if (step > 0)
-          std::copy(scores.begin() + (size_t)src * (ML + 1), scores.begin() + (size_t)src * (ML + 1) + step, scores_new.begin() + (size_t)row * (ML + 1));
-        scores_new[(size_t)row * (ML + 1) + step] = cs[j];
-        h_parent[row] = src;
-        h_tok[row] = ct[j];
-        h_cum[row] = cs[j];
-      }
+    if (trace) {       // parity tests: the step's candidate list as the generator sees it (this path drains the stream)
+      const size_t off = (size_t)step * n * K2;
+      MHIP_HIP(ctx, hipMemcpyAsync(trace->scores + off, d_cs, (size_t)n * K2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+      MHIP_HIP(ctx, hipMemcpyAsync(trace->tokens + off, d_ct, (size_t)n * K2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+      MHIP_HIP(ctx, hipMemcpyAsync(trace->beams + off, d_cb, (size_t)n * K2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+      MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      trace->steps = step + 1;
     }
-    tokens.swap(tokens_new);
-    scores.swap(scores_new);
-    if (remaining == 0) break;
+    if ((rc = mhip_launch_beam_select(ctx, bs, tcur, step))) return rc;
+    tcur ^= 1;
+    MHIP_HIP(ctx, hipMemcpyAsync(&m->h_remaining[step], bs.remaining, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MHIP_HIP(ctx, hipEventRecord(m->rem_ev[step & 1], ctx->stream));
   }
   // best hypothesis per crop: highest score, first finalized wins ties (torch.sort(descending) on the score list)
-  for (int s = 0; s < n; ++s) {
-    int best = -1;
-    for (int j = 0; j < (int)finalized[s].size(); ++j)
-      if (best < 0 || finalized[s][j].score > finalized[s][best].score) best = j;
-    int32_t* to = tokens_out + (size_t)s * (ML + 1);
-    for (int t = 0; t <= ML; ++t) to[t] = c.pad;
-    if (best < 0) { lengths_out[s] = 0; scores_out[s] = -INFINITY; continue; }
-    const Hypo& h = finalized[s][best];
-    for (size_t t = 0; t < h.toks.size() && t < (size_t)ML + 1; ++t) to[t] = h.toks[t];
-    lengths_out[s] = (int32_t)h.toks.size();
-    scores_out[s] = h.score;
-  }
+  if ((rc = mhip_launch_beam_best(ctx, bs, d_out_tok, d_out_len, d_out_score))) return rc;
+  MHIP_HIP(ctx, hipMemcpyAsync(tokens_out, d_out_tok, (size_t)n * (ML + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(lengths_out, d_out_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipMemcpyAsync(scores_out, d_out_score, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MHIP_OK;
 }
 
@@ -483,6 +436,29 @@ extern "C" int mhip_trocr_generate_host(mhip_trocr* m, const uint8_t* crops_host
   if (!rc) rc = trocr_generate(m, dev, n, swap_rb, tokens_out, lengths_out, scores_out, enc_tokens_out, step0_logits_out);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(dev);
+  return rc;
+}
+
+// generate_host + the candidate list of every step as the generator saw it (parity tests: the CPU restatement walks the two
+// searches side by side).  trace_* : host arrays [max_len + 1][n][2 * beam]; *steps_out = steps that ran.
+extern "C" int mhip_trocr_generate_trace_host(mhip_trocr* m, const uint8_t* crops_host, int n, int swap_rb, int32_t* tokens_out,
+                                              int32_t* lengths_out, float* scores_out, float* trace_scores,
+                                              int32_t* trace_tokens, int32_t* trace_beams, int* steps_out) {
+  if (!m || !crops_host || !tokens_out || !lengths_out || !scores_out || !trace_scores || !trace_tokens || !trace_beams ||
+      !steps_out || n < 1)
+    return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t nb = (size_t)n * m->cfg.img_size * m->cfg.img_size * 3;
+  uint8_t* dev = nullptr;
+  MHIP_HIP(ctx, hipMalloc((void**)&dev, nb));
+  hipError_t e = hipMemcpy(dev, crops_host, nb, hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? MHIP_OK : mhip_fail(ctx, MHIP_EHIP, "crop upload: %s", hipGetErrorString(e));
+  TrocrTrace tr{trace_scores, trace_tokens, trace_beams, 0};
+  if (!rc) rc = trocr_generate(m, dev, n, swap_rb, tokens_out, lengths_out, scores_out, nullptr, nullptr, &tr);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dev);
+  *steps_out = tr.steps;
   return rc;
 }
 

@@ -219,7 +219,7 @@ class OcrEngine:
         stop = threading.Event()
         gate = getattr(icr_processor, "decode_gate", None)
         targets: "queue.Queue" = queue.Queue()        # consumer -> producer: the gate signal that opens the next detector batch
-        # processors without a device (the oracle-backed ones of the CPU plumbing tests) overlap as plain host threads
+        # processors without a device (the CPU stand-ins of the plumbing tests) overlap as plain host threads
         on_gpu = torch.cuda.is_available()
         det_stream = torch.cuda.Stream() if on_gpu else None
         det_ctx = getattr(box_processor, "ctx", None) if on_gpu else None

@@ -80,6 +80,22 @@ class TrocrModel:
         res = self._unpack(tokens, lengths, scores)
         return (res, enc, lg) if want_taps else res
 
+    def generate_trace_host(self, crops_u8: np.ndarray, swap_rb: bool = False):
+        """``generate_host`` + the beam search's candidate lists: (hypotheses, {"scores", "tokens", "beams"} each
+        [steps][n][2 * beam]) — what the generator saw at every step (parity tests)."""
+        crops = np.ascontiguousarray(crops_u8, np.uint8)
+        n, k2 = crops.shape[0], 2 * self.cfg.beam
+        tokens, lengths, scores = self._outputs(n)
+        ts = np.zeros((self.max_len + 1, n, k2), np.float32)
+        tt = np.zeros((self.max_len + 1, n, k2), np.int32)
+        tb = np.zeros((self.max_len + 1, n, k2), np.int32)
+        steps = C.c_int(0)
+        check(self.ctx.h, self.lib.mhip_trocr_generate_trace_host(self.h, _vp(crops), n, int(swap_rb), _vp(tokens), _vp(lengths),
+                                                                  _vp(scores), _vp(ts), _vp(tt), _vp(tb), C.byref(steps)),
+              "mhip_trocr_generate_trace_host")
+        k = steps.value
+        return self._unpack(tokens, lengths, scores), {"scores": ts[:k], "tokens": tt[:k], "beams": tb[:k]}
+
     def generate_device(self, crops_ptr: int, n: int, swap_rb: bool = False):
         tokens, lengths, scores = self._outputs(n)
         check(self.ctx.h, self.lib.mhip_trocr_generate(self.h, C.c_void_p(crops_ptr), n, int(swap_rb), _vp(tokens), _vp(lengths),

@@ -486,6 +486,99 @@ def make_trocr_state(seed: int = 0, enc=(768, 12, 12), dec=(1024, 12, 16, 4096),
     return st
 
 
+def make_trocr_sharp_state(seed: int = 0, enc=(768, 12, 12), dec=(1024, 12, 16, 4096), vocab: int = 50265,
+                           max_positions: int = 512, pad: int = 1, img: int = 384, eos: int = 2, top_logit: float = 16.0,
+                           tok_gain: float = 3.0, pos_gain: float = 1.5, img_gain: float = 0.6, sub_gain: float = 0.05,
+                           end_fraction: float = 0.08, fam_gain: float = 0.5) -> Dict[str, np.ndarray]:
+    """Seeded TrOCR weights whose beam search has MARGINS, for parity statements that need them (the reduced-precision run
+    must return the oracle's tokens whenever the oracle's own top-1 / top-2 gaps exceed the measured error many times over).
+    Same architecture and key names as ``make_trocr_state``; what differs is structure in the decoder's two ends:
+
+    * the model dimension is split into a token part (first 3/4) and a family part (last 1/4).  A token's embedding is a
+      random direction in the token part plus a small random vector in the family part; positions live mostly in the family part;
+    * every token has one successor among the even tokens (family A) and one among the odd tokens (family B).  The output
+      projection (untied: ``decoder.output_projection.weight``) of token k holds, in the token part, the embedding directions of
+      the tokens k succeeds (so the two successors of the previous token score ``top_logit`` and everything else a few units),
+      and in the family part +u / -u by k's family: which successor wins is decided by u . x_family, a sum of a term of the
+      previous token (``tok_gain``), of the position (``pos_gain``), of the image through the encoder-attention
+      (``img_gain`` on the family rows of its output projection) and of the small contributions of every other sub-layer
+      (``sub_gain`` on their output projections: they stay alive, the residual stream stays close to the embedding);
+    * ``end_fraction`` of the tokens raise a flag dimension that the ``</s>`` row reads: lines end at different lengths.
+
+    Decisions are binary with a typical margin of several nats, depend on the image, the position and the history, and the
+    runner-up stays in the beam — sequences differ from line to line and within a line."""
+    ed, edepth, eheads = enc
+    D, L, H, F = dec
+    g = img // 16
+    st = {"encoder.deit." + k: v for k, v in
+          make_vit_state(seed, ed, edepth, eheads, pos_hw=(g, g), layer_scale=False, qkv_bias=0, fpn=False, final_norm=True).items()}
+    rng = np.random.Generator(np.random.PCG64(seed + 7368787))
+    DT = D * 3 // 4
+    DF = D - DT - 1                    # family dimensions; the last dimension is the end flag
+    FLAG = D - 1
+
+    def uni(shape, bound):
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    def gauss(shape, std):
+        return (rng.standard_normal(size=shape) * std).astype(np.float32)
+
+    emb = np.zeros((vocab, D), np.float32)
+    emb[:, :DT] = gauss((vocab, DT), 1.0)
+    emb[:, DT:DT + DF] = gauss((vocab, DF), 0.5)
+    ending = rng.random(vocab) < end_fraction
+    ending[:4] = False
+    emb[ending, FLAG] = 4.0
+    st["decoder.embed_tokens.weight"] = emb
+    pos = np.zeros((max_positions + pad + 1, D), np.float32)
+    pos[:, :DT] = gauss((len(pos), DT), 0.1)
+    pos[:, DT:DT + DF] = gauss((len(pos), DF), 0.5)
+    st["decoder.embed_positions.weight"] = pos
+    st["decoder.layernorm_embedding.weight"] = np.ones((D,), np.float32)
+    st["decoder.layernorm_embedding.bias"] = np.zeros((D,), np.float32)
+    for l in range(L):
+        p = f"decoder.layers.{l}."
+        for att, kd in (("self_attn", D), ("encoder_attn", ed)):
+            st[p + att + ".q_proj.weight"] = uni((D, D), 2.0 * np.sqrt(3.0 / D))
+            st[p + att + ".k_proj.weight"] = uni((D, kd), 2.0 * np.sqrt(3.0 / kd))
+            st[p + att + ".v_proj.weight"] = uni((D, kd), np.sqrt(3.0 / kd))
+            w = uni((D, D), sub_gain * np.sqrt(3.0 / D))
+            if att == "encoder_attn":
+                w[DT:DT + DF] *= np.float32(img_gain / sub_gain)
+            st[p + att + ".out_proj.weight"] = w
+            for n in ("q_proj", "k_proj", "v_proj"):
+                st[p + att + f".{n}.bias"] = uni((D,), 0.1)
+            st[p + att + ".out_proj.bias"] = np.zeros((D,), np.float32)
+        st[p + "fc1.weight"] = uni((F, D), np.sqrt(3.0 / D))
+        st[p + "fc1.bias"] = uni((F,), 0.1)
+        st[p + "fc2.weight"] = uni((D, F), sub_gain * np.sqrt(3.0 / F))
+        st[p + "fc2.bias"] = np.zeros((D,), np.float32)
+        for n in ("self_attn_layer_norm", "encoder_attn_layer_norm", "final_layer_norm"):
+            st[p + n + ".weight"] = np.ones((D,), np.float32)
+            st[p + n + ".bias"] = np.zeros((D,), np.float32)
+    # output projection: successors in the token part, family sign in the family part, end flag for </s>
+    ids = np.arange(vocab)
+    n_even = (vocab - 4 + 1) // 2
+    succ_a = 4 + 2 * rng.integers(0, n_even, size=vocab)                       # even tokens >= 4
+    succ_b = 5 + 2 * rng.integers(0, (vocab - 5 + 1) // 2, size=vocab)         # odd tokens >= 5
+    unit = emb[:, :DT] / np.linalg.norm(emb[:, :DT], axis=1, keepdims=True)
+    out = np.zeros((vocab, D), np.float32)
+    a = np.float32(top_logit / np.sqrt(DT))        # a token's own direction has length ~ sqrt(DT) after the last LayerNorm
+    np.add.at(out[:, :DT], succ_a, a * unit)
+    np.add.at(out[:, :DT], succ_b, a * unit)
+    u = gauss((DF,), 1.0)
+    u /= np.linalg.norm(u)
+    fam = np.where(ids % 2 == 0, 1.0, -1.0).astype(np.float32)
+    out[:, DT:DT + DF] = fam[:, None] * u[None, :] * np.float32(fam_gain)
+    out[:4] = 0.0
+    out[eos, FLAG] = np.float32(2.0 * top_logit / 4.0)
+    st["decoder.output_projection.weight"] = out
+    # the family coordinate the decision reads: project the three sources onto u with the requested gains
+    emb[:, DT:DT + DF] += gauss((vocab, 1), tok_gain) * u[None, :]
+    pos[:, DT:DT + DF] += gauss((len(pos), 1), pos_gain) * u[None, :]
+    return st
+
+
 def make_ocr_result(seed: int, width: int, height: int, n_lines: int = 12, page: int = 0) -> dict:
     """A seeded page result in the engine's output layout (``{"meta", "words", "lines"}``, boxes xywh) — synthetic input
     for the step after the path (renderers, ``get_words_and_boxes``): ragged lines, gaps, words of 1..12 characters."""

@@ -116,8 +116,12 @@ class TorchTrocrOracle:
         return out
 
     @torch.no_grad()
-    def generate(self, crops_rgb_u8: np.ndarray, want_step0: bool = False):
-        """Returns per crop (tokens incl. eos, normalised score) of the best hypothesis."""
+    def generate(self, crops_rgb_u8: np.ndarray, want_step0: bool = False, want_trace: bool = False):
+        """Returns per crop (tokens incl. eos, normalised score) of the best hypothesis.  ``want_trace``: also the candidate
+        list of every step as BeamSearch.step produced it, one entry longer than the generator reads (2 * beam + 1: the first
+        candidate that did not make the list bounds the last gap) — {"scores", "tokens", "beams"}: [steps][bsz][2 * beam + 1],
+        "active": [steps][bsz] (False once a crop has finished), "prefixes": per step, per crop, the token prefix of every beam
+        row BEFORE the step (so a candidate (beam, token) names a hypothesis independently of row order)."""
         st = self.st
         beam, K2, eos, pad, ML = self.beam, 2 * self.beam, self.eos, self.pad, self.max_len
         enc = self.encode(crops_rgb_u8)
@@ -138,6 +142,7 @@ class TorchTrocrOracle:
         ignore = torch.zeros(bsz, beam, dtype=torch.bool)
         remaining = bsz
         step0 = None
+        trace = {"scores": [], "tokens": [], "beams": [], "active": [], "prefixes": []}
         for step in range(ML + 1):
             logits = self.decoder_step(tokens[:, step], step, hist, cross)
             if step == 0 and want_step0:
@@ -160,6 +165,14 @@ class TorchTrocrOracle:
             cand_scores = torch.gather(flat, 1, order)
             cand_beams = torch.div(order, self.vocab, rounding_mode="trunc")
             cand_tokens = order.fmod(self.vocab)
+            if want_trace:
+                o7 = torch.argsort(flat, dim=1, descending=True, stable=True)[:, :K2 + 1]
+                trace["scores"].append(torch.gather(flat, 1, o7).numpy().copy())
+                trace["beams"].append(torch.div(o7, self.vocab, rounding_mode="trunc").numpy().copy())
+                trace["tokens"].append(o7.fmod(self.vocab).numpy().copy())
+                trace["active"].append(np.array([not f for f in finished]))
+                trace["prefixes"].append([[tuple(int(v) for v in tokens[s * beam + b, 1:step + 1]) for b in range(beam)]
+                                          for s in range(bsz)])
             new_tokens, new_scores = tokens.clone(), scores.clone()
             parent = torch.arange(M)
             for s in range(bsz):
@@ -199,4 +212,8 @@ class TorchTrocrOracle:
             sc = torch.tensor([h["score"] for h in finalized[s]])
             best = finalized[s][int(torch.sort(sc, descending=True, stable=True)[1][0])]
             out.append((best["tokens"].numpy(), best["score"]))
+        if want_trace:
+            tr = {k: (np.stack(v) if k not in ("prefixes",) else v) for k, v in trace.items()}
+            tr["finalized"] = [[h["score"] for h in finalized[s]] for s in range(bsz)]
+            return (out, step0, tr) if want_step0 else (out, tr)
         return (out, step0) if want_step0 else out

@@ -68,6 +68,36 @@ def test_two_rank_rehearsal_matches_one_rank():
 
 
 @pytest.mark.gpu
+def test_rccl_path_with_one_rank_under_the_launcher():
+    """The driver's N > 1 command line with N = 1: ``python -m torch.distributed.run --nproc-per-node=1 bench.py --gpus 1``.
+    The process group is RCCL (backend nccl, device_id given): the weight arenas go through ``dist.broadcast`` of device
+    buffers and the checksum ``all_gather_object``, the stream leg's ``gather_in_order``, the mixed-DPI leg's store-backed work
+    queue and the ``all_reduce(MAX)`` of the timings all run on it, and ``destroy_process_group`` ends it cleanly.  The results
+    (order-sensitive checksums) equal the launcher-less run's."""
+    import socket
+
+    common = ["--gpus", "1", "--steps", "1", "--warmup", "1", "--pages", "4", "--det-batch", "4", "--decode-len", "3", "--stream-pages", "12",
+              "--mixed-pages", "24", "--no-cpu-baseline", "--no-kernel-timing", "--no-secondary", "--host-steps", "0"]
+    plain = _json_line(_run(common).stdout)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MARIE_BENCH_REHEARSE"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH] + common, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 1
+    assert line["process_group"] == {"backend": "nccl", "world": 1, "arena_checksums_equal": True}
+    assert line["stream"]["pages"] == 12 and line["stream"]["result_checksum"] == plain["stream"]["result_checksum"]
+    assert line["mixed_dpi"]["result_checksum"] == plain["mixed_dpi"]["result_checksum"]
+    assert "process_group" not in plain
+
+
+@pytest.mark.gpu
 def test_all_legs_run_and_the_process_exits_cleanly():
     """The default command's shape at a reduced size with every secondary leg on (engine_api, overlay, det_passes_3, mixed DPI,
     cpu parity sample off): one JSON line with the contract's fields, exit code 0.  Regression: the engine leg's detector thread
