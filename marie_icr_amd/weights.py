@@ -491,7 +491,7 @@ def make_trocr_sharp_state(seed: int = 0, enc=(768, 12, 12), dec=(1024, 12, 16, 
                            tok_gain: float = 3.0, pos_gain: float = 1.5, img_gain: float = 0.6, sub_gain: float = 0.05,
                            end_fraction: float = 0.08, fam_gain: float = 0.5) -> Dict[str, np.ndarray]:
     """Seeded TrOCR weights whose beam search has MARGINS, for parity statements that need them (the reduced-precision run
-    must return the oracle's tokens whenever the oracle's own top-1 / top-2 gaps exceed the measured error many times over).
+    must return the fp32 run's tokens whenever the fp32 top-1 / top-2 gaps exceed the measured error many times over).
     Same architecture and key names as ``make_trocr_state``; what differs is structure in the decoder's two ends:
 
     * the model dimension is split into a token part (first 3/4) and a family part (last 1/4).  A token's embedding is a
