@@ -180,7 +180,7 @@ def _iou_match(ref, got, bar):
 
 def cpu_baseline_dit_trocr(dit_state, trocr_state, trocr_dims, decode_len, n_lines, det, rec, precision):
     """The CPU oracle pipeline on a bounded sample (rank 0, N=1 only): one full 2550x3300 page through the DiT-base
-    detector (one pass) and 4 line crops through TrOCR-base, beam 3; the recognizer time is scaled to n_lines crops.
+    detector (one pass) and its n_lines line crops through TrOCR-base, beam 3, in one batch.
     The same page and crops also go through the GPU models that were just timed, and the two outputs are compared
     (``parity``; the assertions live in tests/test_fullsize_gpu.py)."""
     import torch
@@ -212,25 +212,30 @@ def cpu_baseline_dit_trocr(dit_state, trocr_state, trocr_dims, decode_len, n_lin
     t1 = time.perf_counter()
     enc, dec, vocab = trocr_dims
     orec = TorchTrocrOracle(trocr_state, enc[2], dec[2], beam=3, max_len_b=decode_len)
-    k = 4
-    frags = [page[y:y + h + 1, x:x + w + 1] for x, y, w, h in lines[[0, 7, 19, 33]].tolist()]
+    k = n_lines                                                  # every line of the page: the parity sample below has N = 40
+    frags = [page[y:y + h + 1, x:x + w + 1] for x, y, w, h in lines.tolist()]
     crops = preprocess_fragments(frags)
     t2 = time.perf_counter()
-    ref = orec.generate(crops)
+    ref, otr = orec.generate(crops, want_trace=True)
     t3 = time.perf_counter()
-    per_page = (t1 - t0) + (t3 - t2) / k * n_lines
+    per_page = (t1 - t0) + (t3 - t2)
     base = {"value": 1.0 / per_page, "unit": "pages/s", "cores": threads, "physical_cores": phys, "logical_cpus": logical,
             "kind": "port",
             "sample": f"1 of the same seeded {PAGE_W}x{PAGE_H} pages through the detector oracle ({t1 - t0:.1f} s, "
                       f"{len(boxes)} boxes, torch CPU fp32, {threads} threads — the fastest of 16/32/64/{phys} on a probe window; the host has "
-                      f"{phys} physical cores in the affinity mask) + {k} of "
-                      f"its {n_lines} line crops through the TrOCR oracle ({(t3 - t2) / k:.2f} s/crop, beam 3, "
-                      f"{decode_len}+1 steps), recognizer time scaled to {n_lines} crops"}
+                      f"{phys} physical cores in the affinity mask) + all {k} of "
+                      f"its line crops through the TrOCR oracle in one batch ({(t3 - t2) / k:.2f} s/crop, beam 3, "
+                      f"{decode_len}+1 steps)"}
     # ---- the GPU path on the same inputs ----
+    from oracle import trocr_trace as tt
+
     (gb, gs), = det.detect_host(page[None])
-    got = rec.generate_host(crops)
+    got, gtr = rec.generate_trace_host(crops)
+    walk = tt.walk(otr, gtr)
     equal = [bool(len(g[0]) == len(r[0]) and np.array_equal(g[0], r[0])) for g, r in zip(got, ref)]
     own = orec.score_tokens(crops, [g[0] for g in got])
+    gaps = [float(r[1] - s_) for r, s_ in zip(ref, own)]
+    never = [w["diverged_at"] is None for w in walk]
     parity = {"dtype": precision, "page": "seed 999",
               "boxes": {"oracle": int(len(boxes)), "gpu": int(len(gb)),
                         "matched_iou_0.999": _iou_match(boxes, gb, 0.999), "matched_iou_0.99": _iou_match(boxes, gb, 0.99),
@@ -239,10 +244,22 @@ def cpu_baseline_dit_trocr(dit_state, trocr_state, trocr_dims, decode_len, n_lin
                         # BASELINE.json's second metric ("char-error vs ref"): Levenshtein distance / reference length; the
                         # seeded models have no real vocabulary, so the symbols compared are the token ids
                         "symbol_error_rate": _edit_rate([list(map(int, r[0])) for r in ref], [list(map(int, g[0])) for g in got]),
+                        "symbols": int(sum(len(r[0]) for r in ref)),
                         "max_abs_score_diff_where_equal": max([abs(g[1] - r[1]) for g, r, e in zip(got, ref, equal) if e] or [0.0]),
-                        "oracle_best_minus_oracle_score_of_gpu_hypothesis": [float(r[1] - s_) for r, s_ in zip(ref, own)]},
-              "note": "f16 operands re-order near-tied discrete choices of a random-weight model; the fp32 bars (911/911 boxes "
-                      "at IoU >= 0.999, tokens exact) are asserted in tests/test_fullsize_gpu.py"}
+                        # the two beam searches walked side by side (oracle/trocr_trace.py): a line either takes the oracle's
+                        # decisions at every step, or first differs where the oracle's own candidate list has a near-tie
+                        # under the score error measured on that line
+                        "beam_search_never_diverged": int(sum(never)),
+                        "diverged_at_a_proven_near_tie": int(sum((not n) and w["explained"] for n, w in zip(never, walk))),
+                        "diverged_unexplained": int(sum((not n) and (not w["explained"]) for n, w in zip(never, walk))),
+                        "max_candidate_score_error": float(max(w["eps"] for w in walk)),
+                        "max_oracle_best_minus_oracle_score_of_gpu_hypothesis": float(max(gaps)),
+                        "min_oracle_best_minus_oracle_score_of_gpu_hypothesis": float(min(gaps))},
+              "note": "N = 1 page (its boxes) and its 40 line crops.  f16 operands re-order near-tied discrete choices of a "
+                      "random-weight model: every difference is shown to be a near-tie under the measured error by the interval "
+                      "analysis (detector) and the candidate-list walk (recognizer) in tests/test_fullsize_gpu.py, which also "
+                      "holds the fp32 bars (911 of 911 boxes matched: 900 at IoU >= 0.999, 11 boxes under 16 px by every "
+                      "coordinate within 0.004 px; tokens exact on all 40 lines) and the string-exact bar on the decoder with margins"}
     return base, parity
 
 

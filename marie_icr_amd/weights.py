@@ -489,7 +489,7 @@ def make_trocr_state(seed: int = 0, enc=(768, 12, 12), dec=(1024, 12, 16, 4096),
 def make_trocr_sharp_state(seed: int = 0, enc=(768, 12, 12), dec=(1024, 12, 16, 4096), vocab: int = 50265,
                            max_positions: int = 512, pad: int = 1, img: int = 384, eos: int = 2, top_logit: float = 16.0,
                            tok_gain: float = 3.0, pos_gain: float = 1.5, img_gain: float = 0.6, sub_gain: float = 0.05,
-                           end_fraction: float = 0.08, fam_gain: float = 0.5) -> Dict[str, np.ndarray]:
+                           end_fraction: float = 0.08, fam_gain: float = 0.5, end_gain: float = 2.0) -> Dict[str, np.ndarray]:
     """Seeded TrOCR weights whose beam search has MARGINS, for parity statements that need them (the reduced-precision run
     must return the fp32 run's tokens whenever the fp32 top-1 / top-2 gaps exceed the measured error many times over).
     Same architecture and key names as ``make_trocr_state``; what differs is structure in the decoder's two ends:
@@ -503,7 +503,8 @@ def make_trocr_sharp_state(seed: int = 0, enc=(768, 12, 12), dec=(1024, 12, 16, 
       previous token (``tok_gain``), of the position (``pos_gain``), of the image through the encoder-attention
       (``img_gain`` on the family rows of its output projection) and of the small contributions of every other sub-layer
       (``sub_gain`` on their output projections: they stay alive, the residual stream stays close to the embedding);
-    * ``end_fraction`` of the tokens raise a flag dimension that the ``</s>`` row reads: lines end at different lengths.
+    * ``end_fraction`` of the tokens raise a flag dimension that the ``</s>`` row reads (``end_gain`` x ``top_logit`` for a
+      flag that survived the LayerNorms undiluted): lines end at different lengths.
 
     Decisions are binary with a typical margin of several nats, depend on the image, the position and the history, and the
     runner-up stays in the beam — sequences differ from line to line and within a line."""
@@ -571,7 +572,7 @@ def make_trocr_sharp_state(seed: int = 0, enc=(768, 12, 12), dec=(1024, 12, 16, 
     fam = np.where(ids % 2 == 0, 1.0, -1.0).astype(np.float32)
     out[:, DT:DT + DF] = fam[:, None] * u[None, :] * np.float32(fam_gain)
     out[:4] = 0.0
-    out[eos, FLAG] = np.float32(2.0 * top_logit / 4.0)
+    out[eos, FLAG] = np.float32(end_gain * top_logit / 4.0)
     st["decoder.output_projection.weight"] = out
     # the family coordinate the decision reads: project the three sources onto u with the requested gains
     emb[:, DT:DT + DF] += gauss((vocab, 1), tok_gain) * u[None, :]

@@ -162,10 +162,28 @@ def check_against(cands: Dict[str, np.ndarray], got_boxes: np.ndarray, iou_bar: 
     kept = cands["state"] == KEPT
     missing = np.nonzero(kept & (best_c < iou_bar))[0]
     foreign = np.nonzero(best_g < iou_bar)[0]
+    # how far a box of the other run sits from the candidate it is matched with (the candidate nearest in coordinates among
+    # those that pass the bar): px; relative to the candidate's extent along the axis of each coordinate; and the largest px
+    # deviation among the pairs that are NOT within 0.2 % of the extent (those matched by the coordinate tolerance: small boxes)
+    dev_px = dev_rel = dev_px_small = 0.0
+    if len(got_boxes) and len(cands["boxes"]):
+        cb, gb = cands["boxes"].astype(np.float64), got_boxes.astype(np.float64)
+        d = np.abs(cb[:, None, :] - gb[None, :, :]).max(axis=2)
+        d = np.where(iou >= iou_bar, d, np.inf)
+        j = d.argmin(axis=0)
+        dm = d[j, np.arange(len(gb))]
+        okm = np.isfinite(dm)
+        if okm.any():
+            c, g = cb[j][okm], gb[okm]
+            ext = np.stack([c[:, 2] - c[:, 0], c[:, 3] - c[:, 1]] * 2, axis=1)
+            rel = (np.abs(c - g) / np.clip(ext, 1e-6, None)).max(axis=1)
+            dev_px, dev_rel = float(dm[okm].max()), float(rel.max())
+            dev_px_small = float(dm[okm][rel > 2e-3].max()) if (rel > 2e-3).any() else 0.0
     return {"kept": int(kept.sum()), "unstable": int((~kept).sum()), "got": int(len(got_boxes)),
             "kept_matched": int((kept & (best_c >= iou_bar)).sum()), "missing_kept": missing.tolist(),
             "foreign": foreign.tolist(),
-            "unstable_present": int(((~kept) & (best_c >= iou_bar)).sum())}
+            "unstable_present": int(((~kept) & (best_c >= iou_bar)).sum()),
+            "max_coord_dev_px": dev_px, "max_coord_dev_over_extent": dev_rel, "max_coord_dev_px_of_pairs_beyond_0.2pct": dev_px_small}
 
 
 def explain_end_to_end(oracle, stages: Dict[str, object], out: Dict[str, object], page_hw, margin: float = 1.5
@@ -182,13 +200,22 @@ def explain_end_to_end(oracle, stages: Dict[str, object], out: Dict[str, object]
     anchors = dt.grid_anchors(dt.cell_anchors(), sizes, strides)
     for g, r, anc in zip(out["rpn_heads"], stages["rpn_heads"], anchors):
         lg = torch.from_numpy(np.ascontiguousarray(r[:, :3])).reshape(-1)
-        idx = torch.argsort(lg, descending=True, stable=True)[:1200]
+        srt = torch.sort(lg, descending=True, stable=True)
+        kth = float(srt.values[min(len(lg), 1000) - 1])
+        # every anchor that may reach the top-k under the measured logit error (rpn_intervals' candidate set), at least 1200
+        n_c = max(1200, int((lg >= kth - 2 * es).sum()))
+        idx = srt.indices[:n_c]
         a = dt.apply_deltas(torch.from_numpy(np.ascontiguousarray(r[:, 3:15])).reshape(-1, 4)[idx], anc[idx], (1.0,) * 4)
         b = dt.apply_deltas(torch.from_numpy(np.ascontiguousarray(g[:, 3:15])).reshape(-1, 4)[idx], anc[idx], (1.0,) * 4)
         eb = max(eb, float((a - b).abs().max()))
     eb *= margin
     props = rpn_intervals(stages["rpn_heads"], sizes, strides, (nh, nw), es, eb)
     chk_p = check_against(props, out["proposals"], coord_tol=eb)
+    if chk_p["foreign"]:      # diagnosis: how far the unexplained proposals are from the nearest candidate
+        fb = np.asarray(out["proposals"])[chk_p["foreign"]].astype(np.float64)
+        dd = np.abs(props["boxes"][None, :, :].astype(np.float64) - fb[:, None, :]).max(axis=2)
+        chk_p["foreign_nearest_candidate_px"] = dd.min(axis=1).tolist()
+        chk_p["foreign_boxes"] = fb.tolist()
     nhwc = [np.ascontiguousarray(f) for f in stages["fpn"][:4]]
     head_all = oracle.box_head(dt.roi_align(nhwc, (1 / 4, 1 / 8, 1 / 16, 1 / 32), props["boxes"]))
     dist = np.abs(props["boxes"][:, None, :] - out["proposals"][None, :, :]).max(axis=2)

@@ -11,8 +11,10 @@ Bars (written next to each assertion):
         a partner at IoU >= 0.999 (boxes of a few pixels, whose IoU moves by 0.3 % under a 0.004 px shift: every coordinate
         within the measured error, < 0.01 px) and every extra / missing box is a proven near-tie; TrOCR tokens exact, score
         within 1e-3.  Measured (profiles/r02/a_fullsize_parity.json): 911 / 911 boxes, 0 unstable, max |d coordinate| 0.004 px.
-  f16   (the bench dtype) maps within 3 % of range; box-set match fractions reported and bounded; TrOCR hypotheses equal or a
-        near-tie under the oracle's own scoring (teacher-forced score within 0.005 of the oracle's best).
+  f16   (the bench dtype) maps within 0.5 % of range; the same interval analysis with f16's measured error: every KEPT box
+        matched, every f16 box a KEPT or UNSTABLE candidate, matched pairs within the predicted coordinate error; box-set match
+        fractions reported and bounded; TrOCR: every divergence of the beam search a proven near-tie (40 lines), and on the
+        decoder with margins every certified line string-exact (80 lines).
 Numbers are written to gpurun_out/fullsize_parity.json when that directory exists."""
 import json
 import os
@@ -140,6 +142,7 @@ def test_dit_base_f16_full_page(ctx, page, dit_case):
     from marie_icr_amd._lib import PREC_F16
     from marie_icr_amd.dit import DitModel
     from oracle import dit_torch as dt
+    from oracle import dit_trace as tr
 
     st, o, rboxes, rscores, stages = dit_case
     m = DitModel(ctx, st, model="base", precision=PREC_F16)
@@ -151,7 +154,7 @@ def test_dit_base_f16_full_page(ctx, page, dit_case):
     for f, r in zip(out["fpn"], stages["fpn"]):
         rng_ = float(np.abs(r).max())
         rel.append(float(np.abs(f - r).max()) / rng_)
-        assert np.abs(f - r).max() <= 0.03 * rng_ + 0.02, (np.abs(f - r).max(), rng_)
+        assert np.abs(f - r).max() <= 0.005 * rng_, (np.abs(f - r).max(), rng_)      # 0.5 % of range (measured 0.09 - 0.12 %)
     # the discrete stages are precision-independent: replay the oracle's on the f16 run's own tensors
     nh, nw = stages["resized_hw"]
     ob, os_ = dt.rpn_proposals(out["rpn_heads"], out["sizes"], (4, 8, 16, 32, 64), (nh, nw), dt.cell_anchors())
@@ -165,9 +168,24 @@ def test_dit_base_f16_full_page(ctx, page, dit_case):
            "gpu_boxes": len(out["boxes"]), "matched_iou_0.999": _match(rboxes, out["boxes"], 0.999),
            "matched_iou_0.99": _match(rboxes, out["boxes"], 0.99), "matched_iou_0.9": _match(rboxes, out["boxes"], 0.9),
            "matched_iou_0.5": _match(rboxes, out["boxes"], 0.5)}
+    # ---- the fp32 argument with f16's MEASURED error: interval analysis of the oracle's discrete stages (oracle/dit_trace.py)
+    # eps = 1.5 x the error of this run's own RPN-head / box-head tensors.  Every candidate the oracle keeps under every
+    # perturbation up to eps (KEPT) must be in the f16 run's output — at IoU >= 0.999 or every coordinate within the coordinate
+    # error the measured head error predicts (eps_page_px) — and every box the f16 run returns must be a KEPT or UNSTABLE
+    # candidate: every difference between the two box sets is a proven near-tie, nothing is unexplained on either side.
+    ex = tr.explain_end_to_end(o, stages, out, (PAGE_H, PAGE_W))
+    chk_p, chk = ex["proposals_check"], ex["boxes_check"]
+    rep.update({k: v for k, v in ex.items()})
     _report("dit_base_f16", rep)
+    assert not chk_p["missing_kept"] and not chk_p["foreign"], chk_p
+    assert not chk["missing_kept"] and not chk["foreign"], chk
+    assert chk["kept_matched"] == chk["kept"], chk
+    # matched pairs: a box of the f16 run sits within the predicted coordinate error of the candidate it realises
+    # (within 0.2 % of the box extent = IoU >= 0.999 territory, or within eps_page_px for the small boxes)
+    assert chk["max_coord_dev_px_of_pairs_beyond_0.2pct"] <= ex["eps_page_px"] + 1e-6, (chk, ex["eps_page_px"])
     # random weights make every page position a candidate with near-equal scores, so f16 map noise re-orders many discrete
-    # choices; what is asserted is that the f16 run finds the same structures (count within 10 %, overlap >= 0.5 for 80 %)
+    # choices (the KEPT count says how many of the oracle's decisions have a margin above this run's error); the f16 run still
+    # finds the same structures: count within 10 %, overlap >= 0.5 for 80 %
     assert abs(len(out["boxes"]) - len(rboxes)) <= 0.1 * len(rboxes), rep
     assert rep["matched_iou_0.5"] >= 0.8, rep
 
@@ -350,7 +368,7 @@ def test_trocr_base_f16_model_with_margins_is_string_exact(ctx):
     from marie_icr_amd.weights import make_trocr_sharp_state
     from oracle import trocr_trace as tt
 
-    st = make_trocr_sharp_state(0, top_logit=26.0, fam_gain=1.0, img_gain=1.0, end_fraction=0.04)
+    st = make_trocr_sharp_state(0, top_logit=45.0, fam_gain=12.0, img_gain=1.0, end_fraction=0.15, end_gain=6.0)
     crops = _lines_of([999, 998])
     o, ref, otr, got, gtr, w = _walk_case(ctx, st, crops, PREC_F16)
     eps = max(x["eps"] for x in w)
