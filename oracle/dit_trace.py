@@ -94,7 +94,9 @@ def rpn_intervals(heads: Sequence[np.ndarray], sizes_hw, strides, img_hw, es: fl
         ok = (torch.isfinite(boxes).all(dim=1)).numpy() & np.isfinite(lg)
         boxes = dt.clip_boxes(boxes, img_hw[0], img_hw[1]).numpy()
         w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
-        ok &= (w > 0) & (h > 0)
+        # an empty box of the oracle (clipped to zero height at the image border) may be a sliver in a run whose coordinates
+        # differ by eb: it stays a candidate, as UNSTABLE
+        ok &= (w > -2 * eb) & (h > -2 * eb) & ((w > 0) & (h > 0) | (eb > 0))
         sure &= (w > 2 * eb) & (h > 2 * eb)
         boxes, lg, sure = boxes[ok], lg[ok], sure[ok]
         present = np.where(sure, KEPT, UNSTABLE).astype(np.int8)
