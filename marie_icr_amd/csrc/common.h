@@ -119,7 +119,25 @@ struct ConvDesc {
   int dil = 1;                  // filter dilation
   const void* in2 = nullptr;    // optional second input: channels [Cin1, Cin) of a 1x1 conv over cat(in, in2)
   int Cin1 = 0;
+  // ---- LayerNorm folded around a plain f16 GEMM (the ViT encoder blocks, vit_api.hip) ----
+  // The residual stream x is kept as two f16 planes, x = hi + lo (hi = f16(x), lo = f16(x - hi): ~22 significant bits in the
+  // bytes of one fp32).  hi IS the GEMM operand of the next product: LN(x) W^T = rstd (hi (g*W)^T - mean colsum(g*W)) + W b
+  // up to the rounding of x, so no normalised copy of the stream is ever written.
+  //   EPI_SPLIT    (producer: proj / fc2 / patch embedding) out = hi plane, out2 = lo plane, res / res2 the residual's planes;
+  //                `stats` receives (sum, centred sum of squares) of every output row per 64-column chunk
+  //   EPI_LN_ROWS  (consumer, tokens are GEMM rows: q|k, fc1)  out = act(rstd[m] acc - (mean rstd)[m] cs[n] + bias[n])
+  //   EPI_LN_COLS  (consumer, tokens are GEMM columns: V^T = W_v X^T)  out = rstd[n] acc - (mean rstd)[n] cs[m] + row_bias[m]
+  int epi = 0;
+  const float* ln_a = nullptr;
+  const float* ln_b = nullptr;
+  const float* ln_cs = nullptr;
+  const float* row_bias = nullptr;
+  void* out2 = nullptr;
+  const void* res2 = nullptr;
+  float* stats = nullptr;
+  int stats_ld = 0;
 };
+enum { EPI_NONE = 0, EPI_LN_ROWS = 1, EPI_LN_COLS = 2, EPI_SPLIT = 3 };
 // precision: MHIP_PREC_F16 / MHIP_PREC_F32.  Returns 0 or negative error.
 int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d);
 double mhip_conv_flops(const ConvDesc& d);
@@ -195,8 +213,15 @@ int mhip_launch_rowmax_softmax(mhip_ctx* ctx, const float* logits, int rows, int
 
 // ------------------------------------------------------------------ ViT encoder ops (vit_ops.hip)
 // x: the residual stream, fp32 — or f16 (x_f16, f16 mode only)
+// x_lo: the low plane when the stream is kept as two f16 planes (x = hi + lo; ConvDesc::epi), x then being the high plane
 int mhip_launch_layernorm(mhip_ctx* ctx, int precision, const void* x, const float* g, const float* b, void* out,
-                          int rows, int D, float eps, int x_f16 = 0);
+                          int rows, int D, float eps, int x_f16 = 0, const void* x_lo = nullptr);
+// the split stream (two f16 planes + row statistics per 64-column chunk, stats[(chunk * stats_ld + row) * 2]):
+int mhip_launch_token_init_split(mhip_ctx* ctx, void* hi, void* lo, const float* cls_row, const float* cls_stats, float* stats,
+                                 int stats_ld, int B, int npad, int n_tok, int D);
+int mhip_launch_ln_finalize(mhip_ctx* ctx, const float* stats, int chunks, int ld, float* rstd, float* mur, int rows, int D, float eps);
+int mhip_launch_split_f16(mhip_ctx* ctx, const float* in, void* hi, void* lo, long long n);
+int mhip_launch_join_f16(mhip_ctx* ctx, const void* hi, const void* lo, float* out, long long n);
 // softmax(Q K^T) V for `images` x `heads` independent (head_dim 64) problems; q is pre-scaled by head_dim^-0.5 * log2(e).
 struct AttnDesc {
   const void* q = nullptr;    // [images*npad_q][ldq] T, head h at column h*64

@@ -81,6 +81,19 @@ __device__ __forceinline__ float gelu_erf(float t) {
   return 0.5f * t * (1.f + copysignf(e, x));
 }
 
+// sum over the 8 lanes of an aligned lane group without leaving the VALU (HIP's __shfl_xor is a ds_bpermute: an LDS-crossbar round
+// trip per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7 - i: the other quad's sum)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum8(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  return v;
+}
+
 template <int POOL>
 __device__ __forceinline__ void decode_row(const IgemmArgs& p, int m, int& b, int& y, int& x) {
   if (POOL == POOL_NONE) {
@@ -106,7 +119,7 @@ __device__ __forceinline__ void decode_row(const IgemmArgs& p, int m, int& b, in
   }
 }
 
-template <typename T, int POOL, int BN_, bool DUAL>
+template <typename T, int POOL, int BN_, bool DUAL, int EPI = EPI_NONE>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Cfg<BN_> C;
@@ -356,7 +369,45 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     sc4[j] = (p.scale && n < p.N) ? p.scale[n] : 1.f;
     bi4[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
   }
+  // LayerNorm folded around the GEMM (ConvDesc::epi): the vectors indexed by the GEMM column of this lane
+  //   EPI_LN_ROWS: lnc_b = column sum of the folded weights;  EPI_LN_COLS: lnc_a = rstd, lnc_b = mean * rstd of token n
+  float lnc_a[4] = {1.f, 1.f, 1.f, 1.f}, lnc_b[4] = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == EPI_LN_ROWS || EPI == EPI_LN_COLS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + frow;
+      if (n < p.N) {
+        if (EPI == EPI_LN_ROWS) lnc_b[j] = p.ln_cs[n];
+        else { lnc_a[j] = p.ln_a[n]; lnc_b[j] = p.ln_b[n]; }
+      }
+    }
+  }
+  // ... and the vectors indexed by the GEMM rows of this wave (MT * 16 of them): requested now, parked in a wave-private LDS
+  // strip behind the staging areas once the ring is dead, read back 16 bytes at a time per row-tile (loading them where they are
+  // used put a global-load latency in front of every row-tile)
+  constexpr int WROWS = MT * 16, NRV = (WROWS + 63) / 64;
+  float rv_a[NRV], rv_b[NRV];
+  if (EPI == EPI_LN_ROWS || EPI == EPI_LN_COLS) {
+#pragma unroll
+    for (int k = 0; k < NRV; ++k) {
+      const int m = m0 + wr * WROWS + k * 64 + lane;
+      rv_a[k] = rv_b[k] = 0.f;
+      if (k * 64 + lane < WROWS && m < p.M) {
+        rv_a[k] = (EPI == EPI_LN_ROWS ? p.ln_a : p.ln_cs)[m];
+        rv_b[k] = (EPI == EPI_LN_ROWS ? p.ln_b : p.row_bias)[m];
+      }
+    }
+  }
   __syncthreads();                     // every wave is done reading the ring
+  static_assert(EPI == EPI_NONE || 8 * (2 * 16 * SPW) + 8 * (2 * WROWS * 4) <= C::LDS_BYTES, "row-vector strip");
+  float* rvs = (float*)(smem + 8 * (2 * 16 * SPW) + wave * (2 * WROWS * 4));
+  if (EPI == EPI_LN_ROWS || EPI == EPI_LN_COLS) {
+#pragma unroll
+    for (int k = 0; k < NRV; ++k)
+      if (k * 64 + lane < WROWS) { rvs[k * 64 + lane] = rv_a[k]; rvs[WROWS + k * 64 + lane] = rv_b[k]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
   char* wst0 = smem + wave * (2 * 16 * SPW);   // two private staging areas per wave: tile i+1 is written while tile i drains
   // One specialised copy of the row-tile loop per (output type, residual, GELU) combination, chosen once: the loop is
   // unrolled over the 8 row-tiles (accumulators are registers), so every uniform test left inside it is replicated and
@@ -368,42 +419,78 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   auto body = [&](auto OUT32_, auto RES_, auto GELU_, auto VEC_) {
     constexpr bool OUT32 = decltype(OUT32_)::value, RES = decltype(RES_)::value, GELU = decltype(GELU_)::value,
                    VEC = decltype(VEC_)::value;
+    // EPI_SPLIT: row statistics of the passes this lane keeps (pass = 8 rows x this wave's 64 columns; lane j of an 8-lane
+    // row group keeps pass j of every set of eight), stored once after the loop
+    constexpr int NPASS = MT * ((RT * 8 + 63) / 64), NSET = (NPASS + 7) / 8;
+    float keep_s[NSET], keep_q[NSET];
+#pragma unroll
+    for (int k = 0; k < NSET; ++k) keep_s[k] = keep_q[k] = 0.f;
+    constexpr int NRES32 = RT * 16 / 64, NRES16 = (RT * 8 + 63) / 64;
+    // row-tiles of residual requested ahead of the one being written.  Measured with 2 (tools/ubench/gemm_bench.hip, 369 280 rows):
+    // no gain (proj 0.725 against 0.729 ms fp32, 0.748 against 0.720 ms split) at 26 more registers — these epilogues are bound by
+    // the bytes of the stream (a proj GEMM moves 7.7 KB per row for 1.2 MFLOP: 3.9 TB/s on average, and every CU reaches its
+    // epilogue at the same time), not by the latency of a request; 0 = requested at the top of their own row-tile
+    constexpr int RES_AHEAD = 0;
+    float4v rq32[RES && OUT32 && VEC ? MT : 1][RES && OUT32 && VEC ? NRES32 : 1];
+    half8 rq16[RES && !OUT32 && VEC ? MT : 1][RES && !OUT32 && VEC ? NRES16 : 1];
+    half8 rq16b[EPI == EPI_SPLIT ? MT : 1][EPI == EPI_SPLIT ? NRES16 : 1];
+    auto load_res = [&](int i) {
+      const int qb0 = (m0 + wr * (MT * 16) + i * 16) / PF;
+      if (OUT32) {
+#pragma unroll
+        for (int t = 0; t < NRES32; ++t) {
+          const int cidx = t * 64 + lane, row = cidx >> 4, ch = cidx & 15;
+          const int q = qb0 + row, n = n0 + wc * 64 + ch * 4;
+          rq32[RES && OUT32 && VEC ? i : 0][t] = (float4v){0.f, 0.f, 0.f, 0.f};
+          if (q < Mq && n < p.N) rq32[RES && OUT32 && VEC ? i : 0][t] = *(const float4v*)(p.res + (size_t)res_row(q) * grow + (size_t)n * oe);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NRES16; ++t) {
+          const int cidx = t * 64 + lane, row = cidx >> 3, ch = cidx & 7;
+          const int q = qb0 + row, n = n0 + wc * 64 + ch * 8;
+          rq16[RES && !OUT32 && VEC ? i : 0][t] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+          if (row < RT && q < Mq && n < p.N) rq16[RES && !OUT32 && VEC ? i : 0][t] = *(const half8*)(p.res + (size_t)res_row(q) * grow + (size_t)n * 2);
+          if (EPI == EPI_SPLIT) {
+            rq16b[EPI == EPI_SPLIT ? i : 0][t] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (row < RT && q < Mq && n < p.N) rq16b[EPI == EPI_SPLIT ? i : 0][t] = *(const half8*)(p.res2 + (size_t)res_row(q) * grow + (size_t)n * 2);
+          }
+        }
+      }
+    };
+    if (RES && VEC) {
+#pragma unroll
+      for (int i = 0; i < RES_AHEAD && i < MT; ++i) load_res(i);
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       char* wst = wst0 + (i & 1) * (16 * SPW);
-      // The residual values of this row-tile are requested before its LDS transpose: read next to the store, every one of
-      // the 32 (fp32) / 16 (f16) chunks of a wave paid a full load latency plus the drain of the previous store (vmcnt
-      // counts both), one after the other.  A chunk is read and written by the same lane only, so in-place residuals
-      // (res == out) stay correct.
-      constexpr int NRES32 = RT * 16 / 64, NRES16 = (RT * 8 + 63) / 64;
-      float4v rres32[RES && OUT32 && VEC ? NRES32 : 1];
-      half8 rres16[RES && !OUT32 && VEC ? NRES16 : 1];
-      if (RES && VEC) {
-        const int qb0 = (m0 + wr * (MT * 16) + i * 16) / PF;
-        if (OUT32) {
-#pragma unroll
-          for (int t = 0; t < NRES32; ++t) {
-            const int cidx = t * 64 + lane, row = cidx >> 4, ch = cidx & 15;
-            const int q = qb0 + row, n = n0 + wc * 64 + ch * 4;
-            rres32[t] = (float4v){0.f, 0.f, 0.f, 0.f};
-            if (q < Mq && n < p.N) rres32[t] = *(const float4v*)(p.res + (size_t)res_row(q) * grow + (size_t)n * oe);
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < NRES16; ++t) {
-            const int cidx = t * 64 + lane, row = cidx >> 3, ch = cidx & 7;
-            const int q = qb0 + row, n = n0 + wc * 64 + ch * 8;
-            rres16[t] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (row < RT && q < Mq && n < p.N) rres16[t] = *(const half8*)(p.res + (size_t)res_row(q) * grow + (size_t)n * 2);
-          }
-        }
+      // The residual values of a row-tile are requested RES_AHEAD row-tiles before it is processed (load_res below): read next
+      // to the store, every chunk of a wave paid a full load latency plus the drain of the previous store (vmcnt counts both), one
+      // after the other; requested at the top of their own row-tile (rounds 1-2) the latency of one request per row-tile was
+      // still in front of every row-tile — ~15 us of a 43 us proj tile (tools/ubench/gemm_bench.hip).  A chunk is read and
+      // written by the same lane only, so in-place residuals (res == out) stay correct.
+      if (RES && VEC && i + RES_AHEAD < MT) load_res(i + RES_AHEAD);
+      float4v (&rres32)[RES && OUT32 && VEC ? NRES32 : 1] = rq32[RES && OUT32 && VEC ? i : 0];
+      half8 (&rres16)[RES && !OUT32 && VEC ? NRES16 : 1] = rq16[RES && !OUT32 && VEC ? i : 0];
+      half8 (&rres16b)[EPI == EPI_SPLIT ? NRES16 : 1] = rq16b[EPI == EPI_SPLIT ? i : 0];      // the low plane of a split residual
+      // LayerNorm-folded consumers: the vectors indexed by the four GEMM rows this lane holds of the row-tile
+      //   EPI_LN_ROWS: lr_a = rstd, lr_b = mean * rstd of token m;  EPI_LN_COLS: lr_a = row sum of the folded weights, lr_b = bias
+      float4v lr_a = (float4v){0.f, 0.f, 0.f, 0.f}, lr_b = (float4v){0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_LN_ROWS || EPI == EPI_LN_COLS) {
+        lr_a = *(const float4v*)(rvs + i * 16 + fg * 4);
+        lr_b = *(const float4v*)(rvs + WROWS + i * 16 + fg * 4);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int lc = j * 16 + frow;
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[i][j][r] * sc4[j] + bi4[j], lo);
+        for (int r = 0; r < 4; ++r) {
+          if (EPI == EPI_LN_ROWS) v[r] = acc[i][j][r] * lr_a[r] - lr_b[r] * lnc_b[j] + bi4[j];
+          else if (EPI == EPI_LN_COLS) v[r] = acc[i][j][r] * lnc_a[j] - lnc_b[j] * lr_a[r] + lr_b[r];
+          else v[r] = fmaxf(acc[i][j][r] * sc4[j] + bi4[j], lo);
+        }
         if (POOL == POOL_2x2) {
           lds_put<float>(wst, SPW, fg, lc, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
         } else if (POOL == POOL_2x1) {
@@ -417,7 +504,64 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const int qbase = (m0 + wr * (MT * 16) + i * 16) / PF;
-      if (VEC && !OUT32) {
+      if (EPI == EPI_SPLIT) {
+        // the residual stream as two f16 planes: x = acc * scale + bias + (res_hi + res_lo) in fp32, hi = f16(x), lo = f16(x - hi);
+        // (sum, centred sum of squares) of the row over this wave's 64 columns ride along for the LayerNorm of the consumer
+        half8 hv[NRES16], lv[NRES16];
+        size_t ooff[NRES16];
+        bool ook[NRES16];
+#pragma unroll
+        for (int t = 0; t < NRES16; ++t) {
+          const int cidx = t * 64 + lane;
+          const int row = cidx >> 3, ch = cidx & 7;
+          const int q = qbase + row, n = n0 + wc * 64 + ch * 8;
+          ook[t] = row < RT && q < Mq && n < p.N;
+          ooff[t] = 0;
+          float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (ook[t]) {
+            const float4v a0 = *(const float4v*)(wst + row * SPW + ch * 32), a1 = *(const float4v*)(wst + row * SPW + ch * 32 + 16);
+            const half8 r8 = rres16[t], l8 = rres16b[t];
+            f[0] = a0[0]; f[1] = a0[1]; f[2] = a0[2]; f[3] = a0[3]; f[4] = a1[0]; f[5] = a1[1]; f[6] = a1[2]; f[7] = a1[3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] += (float)r8[k] + (float)l8[k];
+            ooff[t] = (size_t)out_row(q) * grow + (size_t)n * 2;
+          }
+          float sm = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+          sm = sum8(sm);
+          const float mc = sm * (1.f / 64.f);
+          float m2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const float d = f[k] - mc; m2 += d * d; }
+          m2 = sum8(m2);
+          const int pi = i * NRES16 + t;
+          if ((lane & 7) == (pi & 7)) { keep_s[pi >> 3] = sm; keep_q[pi >> 3] = m2; }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            hv[t][k] = (_Float16)f[k];
+            lv[t][k] = (_Float16)(f[k] - (float)hv[t][k]);
+          }
+        }
+        unsigned long long dsth[NRES16], dstl[NRES16];
+#pragma unroll
+        for (int t = 0; t < NRES16; ++t) {
+          dsth[t] = (unsigned long long)(p.out + ooff[t]);
+          dstl[t] = (unsigned long long)(p.out2 + ooff[t]);
+          asm volatile("" : "+v"(dsth[t]), "+v"(dstl[t]), "+v"(hv[t]), "+v"(lv[t]));
+        }
+#pragma unroll
+        for (int t = 0; t < NRES16; ++t)
+          if (ook[t]) {
+            // as the other big tiles: non-temporal (at full batch the planes are gigabytes — they leave the caches before the next
+            // GEMM reads them, and written through they leave the weights in the L2); the few-row tile's stay
+            if (C::SMALL) {
+              *(__attribute__((address_space(1))) half8*)dsth[t] = hv[t];
+              *(__attribute__((address_space(1))) half8*)dstl[t] = lv[t];
+            } else {
+              __builtin_nontemporal_store(hv[t], (__attribute__((address_space(1))) half8*)dsth[t]);
+              __builtin_nontemporal_store(lv[t], (__attribute__((address_space(1))) half8*)dstl[t]);
+            }
+          }
+      } else if (VEC && !OUT32) {
         // f16 out: 8 columns per lane = one 16-byte store; 8 lanes cover a row's 64 columns (128 contiguous bytes).
         // All chunks of the row-tile are produced first and stored together: a store issued between two LDS reads that
         // reuse its data registers makes the compiler drain the store (vmcnt(0)) before every read.
@@ -521,11 +665,36 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
         }
       }
     }
+    if (EPI == EPI_SPLIT) {
+      const int j = lane & 7, g = lane >> 3;
+      if (n0 + wc * 64 < p.N) {
+        const int c64 = (n0 + wc * 64) >> 6;
+#pragma unroll
+        for (int k = 0; k < NSET; ++k) {
+          const int pass = k * 8 + j;
+          if (pass < NPASS) {
+            const int ii = pass / (NPASS / MT), tt = pass % (NPASS / MT);
+            const int q = m0 + wr * (MT * 16) + ii * 16 + tt * 8 + g;
+            if (q < Mq) {
+              float* dst = p.stats + ((size_t)c64 * p.stats_ld + (size_t)out_row(q)) * 2;
+              dst[0] = keep_s[k];
+              dst[1] = keep_q[k];
+            }
+          }
+        }
+      }
+    }
   };
   typedef std::true_type Y;
   typedef std::false_type N_;
   const bool has_res = p.res != nullptr;
-  if (!vec) {
+  if constexpr (EPI == EPI_SPLIT) {
+    body(N_{}, Y{}, N_{}, Y{});
+  } else if constexpr (EPI == EPI_LN_ROWS) {
+    if (gelu) body(N_{}, N_{}, Y{}, Y{}); else body(N_{}, N_{}, N_{}, Y{});
+  } else if constexpr (EPI == EPI_LN_COLS) {
+    body(N_{}, N_{}, N_{}, Y{});
+  } else if (!vec) {
     if (gelu) body(N_{}, N_{}, Y{}, N_{}); else body(N_{}, N_{}, N_{}, N_{});
   } else if (oe == 4) {
     if (gelu) body(Y{}, N_{}, Y{}, Y{}); else if (has_res) body(Y{}, Y{}, N_{}, Y{}); else body(Y{}, N_{}, N_{}, Y{});
@@ -534,9 +703,38 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
   }
 }
 
+// the LayerNorm-folded epilogues (ConvDesc::epi): plain f16 GEMMs on the 256 x 256, 256 x 128 and 128 x 128 tiles
+template <int BN_, int EPI>
+int launch_epi(mhip_ctx* ctx, const IgemmArgs& a, int kid) {
+  dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(NTHREADS);
+  const size_t lds = Cfg<BN_>::LDS_BYTES;
+  static std::once_flag attr_set;
+  std::call_once(attr_set, [&] {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<_Float16, POOL_NONE, BN_, false, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  PROF_LAUNCH(ctx, kid, hipLaunchKernelGGL((conv_igemm_kernel<_Float16, POOL_NONE, BN_, false, EPI>), grid, block, lds, ctx->stream, a));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mhip_fail(ctx, MHIP_EHIP, "conv_igemm launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+template <int BN_>
+int launch_epi_any(mhip_ctx* ctx, const IgemmArgs& a, int kid) {
+  switch (a.epi) {
+    case EPI_LN_ROWS: return launch_epi<BN_, EPI_LN_ROWS>(ctx, a, kid);
+    case EPI_LN_COLS: return launch_epi<BN_, EPI_LN_COLS>(ctx, a, kid);
+    case EPI_SPLIT: return launch_epi<BN_, EPI_SPLIT>(ctx, a, kid);
+    default: return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: unknown epilogue %d", a.epi);
+  }
+}
+
 template <typename T, int BN_>
 int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
   constexpr int KID = BN_ == 64 ? MHIP_K_IGEMM_T64 : (BN_ == 128 ? MHIP_K_IGEMM_T128 : MHIP_K_IGEMM_T256);
+  if (a.epi != EPI_NONE) {
+    if constexpr (std::is_same<T, _Float16>::value && BN_ != 64) return launch_epi_any<BN_>(ctx, a, KID);
+    else return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: a LayerNorm-folded epilogue needs an f16 GEMM with N > 64");
+  }
   dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(NTHREADS);
   const size_t lds = Cfg<BN_>::LDS_BYTES;
   static std::once_flag attr_set;
@@ -575,6 +773,10 @@ int launch_t(mhip_ctx* ctx, const IgemmArgs& a, int pool) {
 // the small 128x128 tile: plain (unpooled, single-input) convs / GEMMs only
 template <typename T>
 int launch_small(mhip_ctx* ctx, const IgemmArgs& a) {
+  if (a.epi != EPI_NONE) {
+    if constexpr (std::is_same<T, _Float16>::value) return launch_epi_any<1128>(ctx, a, MHIP_K_IGEMM_S128);
+    else return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: a LayerNorm-folded epilogue needs an f16 GEMM");
+  }
   dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(NTHREADS);
   const size_t lds = Cfg<1128>::LDS_BYTES;
   static std::once_flag attr_set;
@@ -628,6 +830,23 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
     return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: bad output pitch %d", a.ldc);
   if ((a.res || a.ldc) && ((size_t)(a.ldc ? a.ldc : d.N) * (d.out_f32 ? 4 : esz)) % 16 != 0)
     return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: residual / pitched outputs need 16-byte aligned rows");
+  a.epi = d.epi;
+  a.ln_a = d.ln_a; a.ln_b = d.ln_b; a.ln_cs = d.ln_cs; a.row_bias = d.row_bias;
+  a.out2 = (char*)d.out2; a.res2 = (const char*)d.res2; a.stats = d.stats; a.stats_ld = d.stats_ld;
+  if (d.epi != EPI_NONE) {
+    const long long Mrows = (long long)d.B * d.H * d.W;
+    if (precision != MHIP_PREC_F16 || d.KH != 1 || d.KW != 1 || d.pad != 0 || d.pool != POOL_NONE || d.in2 || d.out_f32 || d.ldc ||
+        d.N % 8 != 0 || (d.epi != EPI_SPLIT && Mrows % 4 != 0) || (d.sy > 1))
+      return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: a LayerNorm-folded epilogue needs a plain f16 GEMM (N %% 8 == 0, M %% 4 == 0)");
+    if (d.epi == EPI_SPLIT && (!d.out2 || !d.res || !d.res2 || !d.stats || d.stats_ld <= 0 || d.N % 64 != 0 || d.relu != ACT_NONE))
+      return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: the split epilogue needs both planes of output and residual, a statistics buffer and N %% 64 == 0");
+    if (d.epi == EPI_LN_ROWS && (!d.ln_a || !d.ln_b || !d.ln_cs || d.res || d.row_period)) return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: EPI_LN_ROWS operands");
+    if (d.epi == EPI_LN_COLS && (!d.ln_a || !d.ln_b || !d.ln_cs || !d.row_bias || d.res || d.relu != ACT_NONE || d.row_period))
+      return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: EPI_LN_COLS operands");
+    if (((unsigned long long)d.out | (unsigned long long)d.out2 | (unsigned long long)d.res | (unsigned long long)d.res2 |
+         (unsigned long long)d.ln_a | (unsigned long long)d.ln_b | (unsigned long long)d.ln_cs | (unsigned long long)d.row_bias) & 15)
+      return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: LayerNorm-folded epilogue operands must be 16-byte aligned");
+  }
   a.in2 = (const char*)d.in2;
   a.Cin1 = d.in2 ? d.Cin1 : d.Cin;
   if (d.in2) {
@@ -659,13 +878,14 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
   a.PH = a.PW = a.tiles_x = a.tiles_y = 0;
   const double fl = ctx->profiling ? mhip_conv_flops(d) : 0.0;
   if (ctx->profiling) ctx->prof[MHIP_K_CONV_IGEMM].flops += fl;
-  {
+  if (d.epi == EPI_NONE) {
     const int r = mhip_try_launch_conv3x3_patch(ctx, precision, d, a);   // 3x3 / pad 1 / dense: patch kernel
     if (r == 0) ctx->prof[MHIP_K_IGEMM_PATCH].flops += fl;
     if (r <= 0) return r;
   }
   static const int force_bn = getenv("MARIE_HIP_FORCE_BN") ? atoi(getenv("MARIE_HIP_FORCE_BN")) : 0;   // tuning aid
-  const int bn = force_bn ? force_bn : ((a.N > 128) ? 256 : (a.N > 64 ? 128 : 64));
+  // (the LayerNorm-folded epilogues exist for the tiles of 128 columns and more)
+  const int bn = force_bn ? force_bn : ((a.N > 128) ? 256 : ((a.N > 64 || d.epi != EPI_NONE) ? 128 : 64));
   const int bm = (bn == 64) ? 512 : 256;
   a.mtiles = (a.M + bm - 1) / bm;
   a.ntiles = (a.N + bn - 1) / bn;
@@ -678,7 +898,7 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
     return precision == MHIP_PREC_F16 ? launch_t<_Float16, 128>(ctx, a, d.pool) : launch_t<float, 128>(ctx, a, d.pool);
   }
   // too few big tiles to occupy the 256 CUs (decoder-step GEMMs, heads on small maps): 128 x 128 tiles instead
-  if (a.mtiles * a.ntiles < 192 && a.N > 64 && d.pool == POOL_NONE && !d.in2) {
+  if (a.mtiles * a.ntiles < 192 && (a.N > 64 || d.epi != EPI_NONE) && d.pool == POOL_NONE && !d.in2) {
     a.mtiles = (a.M + 127) / 128;
     a.ntiles = (a.N + 127) / 128;
     ctx->prof[MHIP_K_IGEMM_S128].flops += fl;

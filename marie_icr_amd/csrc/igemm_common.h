@@ -40,6 +40,16 @@ struct IgemmArgs {
   int row_offset;      //      image's token block (after its cls row) and adds the shared position table
   int PH, PW;          // conv3x3_patch: output patch of one workgroup (PH*PW = 256 pixels)
   int tiles_x, tiles_y;
+  // LayerNorm folded around the GEMM (ConvDesc::epi, f16 plain GEMMs only)
+  int epi;             // EPI_NONE / EPI_LN_ROWS / EPI_LN_COLS / EPI_SPLIT
+  const float* ln_a;   // EPI_LN_ROWS: rstd of GEMM row m;  EPI_LN_COLS: rstd of GEMM column n
+  const float* ln_b;   // mean * rstd, indexed likewise
+  const float* ln_cs;  // EPI_LN_ROWS: column sums of the folded weights [N];  EPI_LN_COLS: row sums [M]
+  const float* row_bias;   // EPI_LN_COLS: bias per GEMM row m
+  char* out2;          // EPI_SPLIT: the low plane of the output (out = high plane), same pitch
+  const char* res2;    // EPI_SPLIT: the low plane of the residual
+  float* stats;        // EPI_SPLIT: per 64-column chunk c and output row r: (sum, centred sum of squares) at stats[(c*stats_ld + r)*2]
+  int stats_ld;
 };
 
 template <typename T>

@@ -47,8 +47,17 @@ extern "C" int mhip_vit_create(mhip_ctx* ctx, int precision, const mhip_vit_conf
   m->precision = precision;
   m->cfg = *cfg;
   m->x16 = precision == MHIP_PREC_F16 && getenv("MARIE_HIP_RESIDUAL_F16") != nullptr;
+  m->fold = precision == MHIP_PREC_F16 && !m->x16 && getenv("MARIE_HIP_NO_LN_FOLD") == nullptr;
   const size_t es = m->esz(), D = cfg->dim, K0 = 3 * 16 * 16;
   Arena& a = m->arena;
+  if (m->fold) {
+    a.take("cls_stats", D / 64 * 2 * 4);
+    for (int i = 0; i < cfg->depth; ++i) {
+      a.take(blk(i, "qk_cs"), 2 * D * 4);
+      a.take(blk(i, "v_cs"), D * 4); a.take(blk(i, "v_rb"), D * 4);
+      a.take(blk(i, "fc1_cs"), 4 * D * 4);
+    }
+  }
   a.take("pe_w", D * K0 * es);
   a.take("pe_b", D * 4);
   a.take("pos", (size_t)cfg->pos_h * cfg->pos_w * D * 4);
@@ -144,6 +153,16 @@ extern "C" int mhip_vit_finalize(mhip_vit* m) {
   memcpy(a.h("pe_b"), pb->data.data(), D * 4);
   memcpy(a.h("pos"), pos->data.data() + D, (size_t)c.pos_h * c.pos_w * D * 4);
   for (int d = 0; d < D; ++d) ((float*)a.h("cls"))[d] = cls->data[d] + pos->data[d];
+  if (m->fold) {   // row statistics of the cls row per 64-column chunk, as conv_igemm's split epilogue produces them for the other rows
+    const float* cr = (const float*)a.h("cls");
+    float* cst = (float*)a.h("cls_stats");
+    for (int c = 0; c < D / 64; ++c) {
+      float sm = 0.f, m2 = 0.f;
+      for (int d = 0; d < 64; ++d) sm += cr[c * 64 + d];
+      for (int d = 0; d < 64; ++d) { const float t = cr[c * 64 + d] - sm / 64.f; m2 += t * t; }
+      cst[c * 2] = sm; cst[c * 2 + 1] = m2;
+    }
+  }
   const float qs = 0.125f * LOG2E;   // head_dim^-0.5 (64 -> 1/8) and the exp -> exp2 change of base, folded into W_q
   for (int i = 0; i < c.depth; ++i) {
     const HostTensor* g1 = st.find(ctx, blk(i, "norm1.weight"), {D});
@@ -201,6 +220,39 @@ extern "C" int mhip_vit_finalize(mhip_vit* m) {
     }
     Arena::put(prec, a.h(blk(i, "fc1_w")), f1w->data.data(), f1w->numel());
     memcpy(a.h(blk(i, "fc1_b")), f1b->data.data(), (size_t)4 * D * 4);
+    if (m->fold) {
+      // LayerNorm folded around its consumer GEMMs:  LN(x) W^T + b = rstd (x (g*W)^T - mean colsum(g*W)) + (b + W beta).
+      // The column sums are those of the ROUNDED folded weights — what the matrix cores multiply — so that the mean term cancels
+      // exactly; the beta term keeps the unrounded weights (it is added in fp32).
+      auto r16 = [](float v) { return (float)(_Float16)v; };
+      auto fold_rows = [&](const float* W, int rows, const std::vector<float>& gam, const std::vector<float>& bet, float pre,
+                           char* w_dst, float* cs, float* beta_dot) {
+        std::vector<float> wf((size_t)rows * D);
+        for (int n = 0; n < rows; ++n) {
+          double c = 0.0, bd = 0.0;
+          for (int k = 0; k < D; ++k) {
+            const float w = W[(size_t)n * D + k] * pre * gam[k];
+            wf[(size_t)n * D + k] = w;
+            c += r16(w);
+            bd += (double)W[(size_t)n * D + k] * pre * bet[k];
+          }
+          cs[n] = (float)c;
+          beta_dot[n] = (float)bd;
+        }
+        Arena::put(prec, w_dst, wf.data(), wf.size());
+      };
+      std::vector<float> bd((size_t)4 * D);
+      float* qkcs = (float*)a.h(blk(i, "qk_cs"));
+      fold_rows(qkv->data.data(), D, g1->data, b1->data, qs, a.h(blk(i, "qk_w")), qkcs, bd.data());
+      for (int d = 0; d < D; ++d) qkb[d] += bd[d];
+      fold_rows(qkv->data.data() + (size_t)D * D, D, g1->data, b1->data, 1.f, a.h(blk(i, "qk_w")) + (size_t)D * D * es, qkcs + D, bd.data());
+      for (int d = 0; d < D; ++d) qkb[D + d] += bd[d];
+      fold_rows(qkv->data.data() + (size_t)2 * D * D, D, g1->data, b1->data, 1.f, a.h(blk(i, "v_w")), (float*)a.h(blk(i, "v_cs")),
+                (float*)a.h(blk(i, "v_rb")));
+      fold_rows(f1w->data.data(), 4 * D, g2->data, b2->data, 1.f, a.h(blk(i, "fc1_w")), (float*)a.h(blk(i, "fc1_cs")), bd.data());
+      float* f1bb = (float*)a.h(blk(i, "fc1_b"));
+      for (int d = 0; d < 4 * D; ++d) f1bb[d] += bd[d];
+    }
     Arena::put(prec, a.h(blk(i, "fc2_w")), f2w->data.data(), f2w->numel());
     float* fs = (float*)a.h(blk(i, "fc2_s"));
     float* fb = (float*)a.h(blk(i, "fc2_b"));
@@ -264,6 +316,7 @@ size_t vit_workspace_bytes(const mhip_vit* m, int B, const VitGeom& g) {
   add(R * 4 * D * es);         // mlp hidden; also the patch matrix
   if (m->cfg.fpn) add(4 * (size_t)B * g.np * D * es);
   else add((R + 64) * D * es); // final tokens (+ slack rows)
+  if (m->fold) { add(D / 64 * R * 8); add(R * 4); add(R * 4); }   // row statistics per chunk, rstd, mean * rstd
   return b;
 }
 
@@ -292,6 +345,9 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
     if (x16) {
       MHIP_HIP(ctx, hipMalloc(&pos16, (size_t)g.np * D * 2));
       if ((rc = mhip_launch_narrow_f16(ctx, pos_dev, pos16, (long long)g.np * D))) return rc;
+    } else if (m->fold) {
+      MHIP_HIP(ctx, hipMalloc(&pos16, (size_t)g.np * D * 4));
+      if ((rc = mhip_launch_split_f16(ctx, pos_dev, pos16, (char*)pos16 + (size_t)g.np * D * 2, (long long)g.np * D))) return rc;
     }
     m->pos_tables.push_back({g.hp, g.wp, pos_dev, pos16});
   }
@@ -306,37 +362,84 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
   char* ao = ws.take(R * D * es);
   char* hid = ws.take(R * 4 * D * es);
   run->x = x;
+  const bool fold = m->fold && prec == MHIP_PREC_F16 && !x16;
+  const int chunks = D / 64;
+  char* xlo = fold ? (char*)x + R * D * 2 : nullptr;          // the split stream: two f16 planes in the bytes of the fp32 one
+  run->x_lo = xlo;
+  float* stats = nullptr; float* rstd = nullptr; float* mur = nullptr;
+  if (fold) {
+    stats = ws.take<float>((size_t)chunks * R * 8);
+    rstd = ws.take<float>(R * 4);
+    mur = ws.take<float>(R * 4);
+  }
   int rc;
   // patches -> hid (as the [B*np][768] patch matrix) -> x rows 1.. with bias + resized position table
   const int K0 = 3 * P * P;
   {   // all images at once: row q of the patch matrix -> token row (q / np) * npad + 1 + q % np, + position row q % np
     if ((rc = mhip_launch_patchify(ctx, prec, imgs, B, th, tw, g.hp, g.wp, P, swap_rb, 127.5f, 127.5f, hid, K0))) return rc;
     ConvDesc cd;
-    cd.in = hid; cd.w = a.d("pe_w"); cd.bias = a.d<float>("pe_b"); cd.out = x; cd.res = x16 ? pos16 : (void*)pos_dev;
-    cd.B = 1; cd.H = 1; cd.W = B * g.np; cd.Cin = K0; cd.N = D; cd.out_f32 = x16 ? 0 : 1;
+    cd.in = hid; cd.w = a.d("pe_w"); cd.bias = a.d<float>("pe_b"); cd.out = x; cd.res = (x16 || fold) ? pos16 : (void*)pos_dev;
+    cd.B = 1; cd.H = 1; cd.W = B * g.np; cd.Cin = K0; cd.N = D; cd.out_f32 = (x16 || fold) ? 0 : 1;
     cd.row_period = g.np; cd.row_stride = g.npad; cd.row_offset = 1;
+    if (fold) { cd.epi = EPI_SPLIT; cd.out2 = xlo; cd.res2 = (char*)pos16 + (size_t)g.np * D * 2; cd.stats = stats; cd.stats_ld = (int)R; }
     if ((rc = mhip_launch_conv_igemm(ctx, prec, cd))) return rc;
   }
-  if ((rc = mhip_launch_token_init(ctx, x, a.d<float>("cls"), B, g.npad, g.n_tok, D, x16))) return rc;
+  if (fold) {
+    if ((rc = mhip_launch_token_init_split(ctx, x, xlo, a.d<float>("cls"), a.d<float>("cls_stats"), stats, (int)R, B, g.npad, g.n_tok, D))) return rc;
+  } else if ((rc = mhip_launch_token_init(ctx, x, a.d<float>("cls"), B, g.npad, g.n_tok, D, x16))) return rc;
+  // split stream: the producers of x (GEMMs with the split epilogue: out = x in place, statistics of the new rows) and the
+  // consumers of LN(x) (GEMMs over the high plane with the folded epilogues)
+  auto produce = [&](const void* in, const void* w, int K, const float* sc, const float* bi) {
+    ConvDesc c;
+    c.in = in; c.w = w; c.scale = sc; c.bias = bi; c.out = x; c.out2 = xlo; c.res = x; c.res2 = xlo;
+    c.B = 1; c.H = 1; c.W = (int)R; c.Cin = K; c.N = D;
+    c.epi = EPI_SPLIT; c.stats = stats; c.stats_ld = (int)R;
+    return mhip_launch_conv_igemm(ctx, prec, c);
+  };
+  auto consume_rows = [&](const void* w, int N, const float* cs, const float* bi, void* out, int act) {
+    ConvDesc c;
+    c.in = x; c.w = w; c.bias = bi; c.out = out;
+    c.B = 1; c.H = 1; c.W = (int)R; c.Cin = D; c.N = N; c.relu = act;
+    c.epi = EPI_LN_ROWS; c.ln_a = rstd; c.ln_b = mur; c.ln_cs = cs;
+    return mhip_launch_conv_igemm(ctx, prec, c);
+  };
   int tap_at = 0;
   if (c.fpn) for (int j = 0; j < 4; ++j) run->tap[j] = ws.take((size_t)B * g.np * D * es);
   for (int i = 0; i < c.depth; ++i) {
+    if (fold) {
+      if ((rc = mhip_launch_ln_finalize(ctx, stats, chunks, (int)R, rstd, mur, (int)R, D, c.ln_eps))) return rc;
+      if ((rc = consume_rows(a.d(blk(i, "qk_w")), 2 * D, a.d<float>(blk(i, "qk_cs")), a.d<float>(blk(i, "qk_b")), qk, ACT_NONE))) return rc;
+      ConvDesc cv;      // V^T = W_v LN(X)^T: the tokens are the GEMM's columns
+      cv.in = a.d(blk(i, "v_w")); cv.w = x; cv.out = vt;
+      cv.B = 1; cv.H = 1; cv.W = D; cv.Cin = D; cv.N = (int)R;
+      cv.epi = EPI_LN_COLS; cv.ln_a = rstd; cv.ln_b = mur; cv.ln_cs = a.d<float>(blk(i, "v_cs")); cv.row_bias = a.d<float>(blk(i, "v_rb"));
+      if ((rc = mhip_launch_conv_igemm(ctx, prec, cv))) return rc;
+    } else {
     if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>(blk(i, "ln1_g")), a.d<float>(blk(i, "ln1_b")), ln, (int)R, D, c.ln_eps, x16))) return rc;
     if ((rc = gemm(ctx, prec, ln, a.d(blk(i, "qk_w")), (long long)R, 2 * D, D, nullptr, a.d<float>(blk(i, "qk_b")), qk, ACT_NONE, 0))) return rc;
     if ((rc = gemm(ctx, prec, a.d(blk(i, "v_w")), ln, D, (int)R, D, nullptr, nullptr, vt, ACT_NONE, 0))) return rc;   // V^T = W_v X^T
+    }
     AttnDesc ad;
     ad.q = qk; ad.k = qk + (size_t)D * es; ad.vt = vt; ad.out = ao;
     ad.ldq = ad.ldk = 2 * D; ad.ldv = (int)R; ad.ldo = D;
     ad.images = B; ad.heads = c.heads; ad.npad_q = ad.npad_k = g.npad; ad.n_queries = ad.n_keys = g.n_tok;
     if ((rc = mhip_launch_attention(ctx, prec, ad))) return rc;
+    if (fold) {
+      if ((rc = produce(ao, a.d(blk(i, "proj_w")), D, a.d<float>(blk(i, "proj_s")), a.d<float>(blk(i, "proj_b"))))) return rc;
+      if ((rc = mhip_launch_ln_finalize(ctx, stats, chunks, (int)R, rstd, mur, (int)R, D, c.ln_eps))) return rc;
+      if ((rc = consume_rows(a.d(blk(i, "fc1_w")), 4 * D, a.d<float>(blk(i, "fc1_cs")), a.d<float>(blk(i, "fc1_b")), hid, ACT_GELU))) return rc;
+      if ((rc = produce(hid, a.d(blk(i, "fc2_w")), 4 * D, a.d<float>(blk(i, "fc2_s")), a.d<float>(blk(i, "fc2_b"))))) return rc;
+    } else {
     if ((rc = gemm(ctx, prec, ao, a.d(blk(i, "proj_w")), (long long)R, D, D, a.d<float>(blk(i, "proj_s")), a.d<float>(blk(i, "proj_b")), x, ACT_NONE, x16 ? 0 : 1, x))) return rc;
     if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>(blk(i, "ln2_g")), a.d<float>(blk(i, "ln2_b")), ln, (int)R, D, c.ln_eps, x16))) return rc;
     if ((rc = gemm(ctx, prec, ln, a.d(blk(i, "fc1_w")), (long long)R, 4 * D, D, nullptr, a.d<float>(blk(i, "fc1_b")), hid, ACT_GELU, 0))) return rc;
     if ((rc = gemm(ctx, prec, hid, a.d(blk(i, "fc2_w")), (long long)R, D, 4 * D, a.d<float>(blk(i, "fc2_s")), a.d<float>(blk(i, "fc2_b")), x, ACT_NONE, x16 ? 0 : 1, x))) return rc;
+    }
     if (c.fpn)
       for (int j = 0; j < 4; ++j)
         if (c.taps[j] == i) {
-          if ((rc = mhip_launch_tokens_to_map(ctx, prec, x, run->tap[j], B, g.npad, g.np, D, x16))) return rc;
+          // a map in f16 of a split stream is its high plane (hi = f16(x))
+          if ((rc = mhip_launch_tokens_to_map(ctx, prec, x, run->tap[j], B, g.npad, g.np, D, x16 || fold))) return rc;
           ++tap_at;
         }
   }
@@ -346,7 +449,7 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
     // past the last image
     run->tokens = ws.take((R + 64) * D * es);
     MHIP_HIP(ctx, hipMemsetAsync(run->tokens + R * D * es, 0, (size_t)64 * D * es, ctx->stream));
-    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>("norm_g"), a.d<float>("norm_b"), run->tokens, (int)R, D, c.ln_eps, x16))) return rc;
+    if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>("norm_g"), a.d<float>("norm_b"), run->tokens, (int)R, D, c.ln_eps, x16 || fold, xlo))) return rc;
   }
   (void)tap_at;
   return MHIP_OK;
@@ -416,7 +519,12 @@ extern "C" int mhip_vit_forward_host(mhip_vit* m, const uint8_t* imgs_host, int 
         MHIP_HIP(ctx, hipMemcpyAsync(tokens_out + (size_t)b * g.n_tok * D, stage, (size_t)g.n_tok * D * 4, hipMemcpyDeviceToHost, ctx->stream));
         MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
       } else {
-        if (m->x16 && m->precision == MHIP_PREC_F16) {      // f16 stream: widen through the staging buffer
+        if (run.x_lo) {      // split stream: hi + lo through the staging buffer
+          const size_t o = (size_t)b * g.npad * D * 2;
+          if ((rc = mhip_launch_join_f16(ctx, (const char*)run.x + o, (const char*)run.x_lo + o, stage, (long long)g.n_tok * D))) return rc;
+          MHIP_HIP(ctx, hipMemcpyAsync(tokens_out + (size_t)b * g.n_tok * D, stage, (size_t)g.n_tok * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+          MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        } else if (m->x16 && m->precision == MHIP_PREC_F16) {      // f16 stream: widen through the staging buffer
           if ((rc = mhip_launch_convert_rows(ctx, m->precision, (const char*)run.x + (size_t)b * g.npad * D * 2, stage, g.n_tok, (int)D))) return rc;
           MHIP_HIP(ctx, hipMemcpyAsync(tokens_out + (size_t)b * g.n_tok * D, stage, (size_t)g.n_tok * D * 4, hipMemcpyDeviceToHost, ctx->stream));
           MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -10,8 +10,13 @@ struct mhip_vit {
   Arena arena;
   // position tables resized to the patch grids seen so far (mixed-DPI streams alternate between a few page sizes);
   // built once per geometry, never inside a steady-state forward
-  struct PosTable { int hp, wp; float* dev; void* dev16; };   // dev16: the same table in f16 (f16 residual stream), or null
+  // dev16: the same table in f16 (f16 residual stream) — or, when the stream is split, its high plane followed by its low plane
+  struct PosTable { int hp, wp; float* dev; void* dev16; };
   bool x16 = false;            // f16 mode with an f16 residual stream (as the reference's .half() path): MARIE_HIP_RESIDUAL_F16
+  // f16 mode, default: the residual stream is kept as two f16 planes (x = hi + lo, ~22 significant bits) and every LayerNorm in
+  // front of a GEMM is folded around that GEMM (common.h, ConvDesc::epi): hi is the operand, the row statistics come out of the
+  // producing GEMM's epilogue.  MARIE_HIP_NO_LN_FOLD=1 when the model is created restores the fp32 stream + LayerNorm passes.
+  bool fold = false;
   std::vector<PosTable> pos_tables;
   bool ready = false;
   size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
@@ -25,7 +30,8 @@ struct VitGeom {
 
 struct VitRun {
   VitGeom g;
-  void* x = nullptr;          // residual stream [B*npad][D]: fp32, or f16 when the model keeps an f16 stream
+  void* x = nullptr;          // residual stream [B*npad][D]: fp32, or f16 when the model keeps an f16 stream, or (split) the high plane
+  void* x_lo = nullptr;       // split stream: the low plane
   char* tap[4] = {nullptr};   // T [B*np][D] patch tokens after blocks cfg.taps[j]
   char* tokens = nullptr;     // T [B*npad][D] after the final norm (final_norm models)
 };

@@ -27,10 +27,11 @@ constexpr int HD = 64;            // head dim of every model on this path (768/1
 // ------------------------------------------------------------------------------------------------------- LayerNorm
 // one wave per row; D % 256 == 0, D <= 1024.  Two-pass (mean, then centred variance) in registers, fp32.  XT: element type of the
 // residual stream that is normalised (fp32, or f16 when the model keeps an f16 stream as the reference's .half() path does).
+// xlo: the low plane of a split stream (x = hi + lo, two f16 planes), or null.
 template <typename T, typename XT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, T* __restrict__ out, int rows,
-                                                        int D, float eps) {
+                                                        int D, float eps, const _Float16* __restrict__ xlo = nullptr) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const int nv = D >> 8;   // 4-element groups per lane
@@ -45,6 +46,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
         typedef _Float16 half4 __attribute__((ext_vector_type(4)));
         const half4 h = *(const half4*)((const _Float16*)x + (size_t)row * D + (i * 64 + lane) * 4);
         v[i] = (float4v){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        if (xlo) {
+          const half4 l = *(const half4*)(xlo + (size_t)row * D + (i * 64 + lane) * 4);
+          v[i] += (float4v){(float)l[0], (float)l[1], (float)l[2], (float)l[3]};
+        }
       }
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
@@ -358,6 +363,66 @@ __global__ void token_init_kernel(XT* x, const float* cls_row, int B, int npad, 
   }
 }
 
+// The split stream (x = hi + lo, two f16 planes; conv_igemm's EPI_SPLIT keeps it): cls row and pad rows of every image, and their
+// row statistics per 64-column chunk — (sum, centred sum of squares), the cls row's precomputed on the host (cls_stats[chunk][2])
+__global__ void token_init_split_kernel(_Float16* hi, _Float16* lo, const float* cls_row, const float* cls_stats, float* stats,
+                                        int stats_ld, int B, int npad, int n_tok, int D) {
+  const int rows_per = 1 + (npad - n_tok);
+  const long long total = (long long)B * rows_per * D;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int d = (int)(e % D);
+    const int r = (int)((e / D) % rows_per), b = (int)(e / ((long long)D * rows_per));
+    const int row = r == 0 ? 0 : n_tok + r - 1;
+    const float v = r == 0 ? cls_row[d] : 0.f;
+    const _Float16 h = (_Float16)v;
+    const size_t o = ((size_t)b * npad + row) * D + d;
+    hi[o] = h;
+    lo[o] = (_Float16)(v - (float)h);
+    if ((d & 63) == 0) {
+      const int c = d >> 6;
+      float* st = stats + ((size_t)c * stats_ld + (size_t)b * npad + row) * 2;
+      st[0] = r == 0 ? cls_stats[c * 2] : 0.f;
+      st[1] = r == 0 ? cls_stats[c * 2 + 1] : 0.f;
+    }
+  }
+}
+
+// row statistics of the split stream -> rstd and mean * rstd per row.  stats[(chunk * ld + row) * 2] = (sum, centred sum of squares)
+// of the row over the 64 columns of the chunk; merged the pairwise way (Chan et al.): no cancellation of large means.
+__global__ void ln_finalize_kernel(const float* __restrict__ stats, int chunks, int ld, float* __restrict__ rstd,
+                                   float* __restrict__ mur, int rows, int D, float eps) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float s[16], q[16], tot = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if (c < chunks) {
+      const float2 v = *(const float2*)(stats + ((size_t)c * ld + r) * 2);
+      s[c] = v.x; q[c] = v.y; tot += v.x;
+    }
+  const float mean = tot / (float)D;
+  float m2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if (c < chunks) { const float d = s[c] * (1.f / 64.f) - mean; m2 += q[c] + 64.f * d * d; }
+  const float rs = 1.f / sqrtf(m2 / (float)D + eps);
+  rstd[r] = rs;
+  mur[r] = mean * rs;
+}
+
+__global__ void split_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ hi, _Float16* __restrict__ lo, long long n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const float v = in[e];
+    const _Float16 h = (_Float16)v;
+    hi[e] = h;
+    lo[e] = (_Float16)(v - (float)h);
+  }
+}
+
+__global__ void join_f16_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, float* __restrict__ out, long long n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) out[e] = (float)hi[e] + (float)lo[e];
+}
+
 // fp32 tokens (without cls) -> T feature map rows [B][n_tok-1][D]
 template <typename T, typename XT>
 __global__ void tokens_to_map_kernel(const XT* __restrict__ x, T* __restrict__ out, int B, int npad, int np, int D) {
@@ -465,12 +530,13 @@ inline int grid_for(long long total, int block) { return (int)std::min<long long
   } while (0)
 
 int mhip_launch_layernorm(mhip_ctx* ctx, int precision, const void* x, const float* g, const float* b, void* out,
-                          int rows, int D, float eps, int x_f16) {
+                          int rows, int D, float eps, int x_f16, const void* x_lo) {
   if (D % 256 != 0 || D > 1024 || rows <= 0) return mhip_fail(ctx, MHIP_EINVAL, "layernorm: D=%d rows=%d", D, rows);
   if (x_f16 && precision != MHIP_PREC_F16) return mhip_fail(ctx, MHIP_EINVAL, "layernorm: an f16 stream needs the f16 mode");
+  if (x_lo && !x_f16) return mhip_fail(ctx, MHIP_EINVAL, "layernorm: a low plane belongs to an f16 high plane");
   dim3 grid((rows + 3) / 4), block(256);
   if (precision == MHIP_PREC_F16 && x_f16)
-    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL((layernorm_kernel<_Float16, _Float16>), grid, block, 0, ctx->stream, (const _Float16*)x, g, b, (_Float16*)out, rows, D, eps));
+    PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL((layernorm_kernel<_Float16, _Float16>), grid, block, 0, ctx->stream, (const _Float16*)x, g, b, (_Float16*)out, rows, D, eps, (const _Float16*)x_lo));
   else if (precision == MHIP_PREC_F16)
     PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL((layernorm_kernel<_Float16, float>), grid, block, 0, ctx->stream, (const float*)x, g, b, (_Float16*)out, rows, D, eps));
   else
@@ -532,6 +598,34 @@ int mhip_launch_token_init(mhip_ctx* ctx, void* x, const float* cls_row, int B, 
   else
     PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(token_init_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, (float*)x, cls_row, B, npad, n_tok, D));
   CHECK_LAUNCH(ctx, "token_init");
+  return 0;
+}
+
+int mhip_launch_token_init_split(mhip_ctx* ctx, void* hi, void* lo, const float* cls_row, const float* cls_stats, float* stats,
+                                 int stats_ld, int B, int npad, int n_tok, int D) {
+  if (D % 64 != 0 || D > 1024) return mhip_fail(ctx, MHIP_EINVAL, "token_init_split: D=%d", D);
+  const long long total = (long long)B * (1 + npad - n_tok) * D;
+  PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(token_init_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, (_Float16*)hi, (_Float16*)lo, cls_row, cls_stats, stats, stats_ld, B, npad, n_tok, D));
+  CHECK_LAUNCH(ctx, "token_init_split");
+  return 0;
+}
+
+int mhip_launch_ln_finalize(mhip_ctx* ctx, const float* stats, int chunks, int ld, float* rstd, float* mur, int rows, int D, float eps) {
+  if (chunks < 1 || chunks > 16 || chunks * 64 != D || rows <= 0) return mhip_fail(ctx, MHIP_EINVAL, "ln_finalize: chunks=%d D=%d rows=%d", chunks, D, rows);
+  PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, stats, chunks, ld, rstd, mur, rows, D, eps));
+  CHECK_LAUNCH(ctx, "ln_finalize");
+  return 0;
+}
+
+int mhip_launch_split_f16(mhip_ctx* ctx, const float* in, void* hi, void* lo, long long n) {
+  PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(split_f16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, in, (_Float16*)hi, (_Float16*)lo, n));
+  CHECK_LAUNCH(ctx, "split_f16");
+  return 0;
+}
+
+int mhip_launch_join_f16(mhip_ctx* ctx, const void* hi, const void* lo, float* out, long long n) {
+  PROF_LAUNCH(ctx, MHIP_K_VIT_OPS, hipLaunchKernelGGL(join_f16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, (const _Float16*)hi, (const _Float16*)lo, out, n));
+  CHECK_LAUNCH(ctx, "join_f16");
   return 0;
 }
 

@@ -82,7 +82,8 @@ def walk(oracle_trace: Dict[str, np.ndarray], gpu_trace: Dict[str, np.ndarray], 
 
 def certificate(oracle_trace: Dict[str, np.ndarray], hyps: Sequence, finalized_scores: Sequence[Sequence[float]], eos: int,
                 eps: float, factor: float = 10.0) -> List[Dict[str, object]]:
-    """Per crop: does the oracle's own run carry margins ``factor`` x ``eps`` everywhere it matters?
+    """Per crop: does the oracle's own run carry margins ``factor`` x ``eps`` everywhere it matters?  (``eps``: one bound, or one
+    per crop — the score error ``walk`` measured on that crop's own candidates.)
     (1) its best hypothesis is the chain of top-1 candidates (each continuing the previous one: row 0), ending in </s>;
     (2) every top-1 / top-2 gap of cumulative score along the chain is at least ``factor * eps``;
     (3) its normalised score leads every other finished hypothesis of the oracle by at least ``factor * eps / length``.
@@ -104,6 +105,7 @@ def certificate(oracle_trace: Dict[str, np.ndarray], hyps: Sequence, finalized_s
         chain_ok = chain_ok and L > 0 and tokens[-1] == eos
         others = sorted((float(v) for v in finalized_scores[s]), reverse=True)[1:]
         lead = float(score) - others[0] if others else float("inf")
-        holds = bool(chain_ok and min_gap >= factor * eps and lead >= factor * eps / max(L, 1))
+        e_s = float(eps[s]) if hasattr(eps, "__len__") else float(eps)        # one bound for all crops, or the one measured per crop
+        holds = bool(chain_ok and min_gap >= factor * e_s and lead >= factor * e_s / max(L, 1))
         out.append({"holds": holds, "min_gap": min_gap, "final_lead": lead, "chain": chain_ok})
     return out

@@ -360,8 +360,8 @@ def test_trocr_base_f16_model_with_margins_is_string_exact(ctx):
     decoder's two ends (two designed successors per token, the winner decided by the previous token, the position and the
     image; marie_icr_amd/weights.py) so that the oracle's own search has margins.  80 lines (two seeded pages).  For every line whose
     oracle run carries the certificate of oracle/trocr_trace.py — best hypothesis = chain of top-1 candidates, every top-1 /
-    top-2 gap of cumulative score >= 10 x the f16 score error MEASURED on these lines, lead over the other finished hypotheses
-    >= 10 x that error / length — the f16 run must return the same tokens; there must be at least 40 such lines; every other
+    top-2 gap of cumulative score >= 10 x the f16 score error MEASURED on that line's candidates, lead over the other finished
+    hypotheses >= 10 x that error / length — the f16 run must return the same tokens; there must be at least 40 such lines; every other
     line is equal or diverges at a proven near-tie.  Sequences are not degenerate: no immediate repeats, several different
     strings, lines ending at different lengths."""
     from marie_icr_amd._lib import PREC_F16
@@ -372,11 +372,14 @@ def test_trocr_base_f16_model_with_margins_is_string_exact(ctx):
     crops = _lines_of([999, 998])
     o, ref, otr, got, gtr, w = _walk_case(ctx, st, crops, PREC_F16)
     eps = max(x["eps"] for x in w)
-    cert = tt.certificate(otr, ref, otr["finalized"], eos=2, eps=eps, factor=10.0)
+    # the error bound of a line: what the walk measured on that line's own candidates (every step of a line that never diverged),
+    # never less than the median over the lines
+    med = float(np.median([x["eps"] for x in w]))
+    cert = tt.certificate(otr, ref, otr["finalized"], eos=2, eps=[max(x["eps"], med) for x in w], factor=10.0)
     equal = [bool(len(g[0]) == len(r[0]) and np.array_equal(g[0], r[0])) for g, r in zip(got, ref)]
     held = [c["holds"] for c in cert]
     strings = {tuple(int(v) for v in r[0]) for r in ref}
-    rep = {"lines": len(crops), "measured_score_error": eps, "certified_lines": int(sum(held)),
+    rep = {"lines": len(crops), "measured_score_error": eps, "median_line_score_error": med, "certified_lines": int(sum(held)),
            "certified_and_equal": int(sum(h and e for h, e in zip(held, equal))), "tokens_equal": int(sum(equal)),
            "never_diverged": int(sum(x["diverged_at"] is None for x in w)), "distinct_strings": len(strings),
            "lengths": sorted({len(r[0]) for r in ref}), "min_certified_gap": min([c["min_gap"] for c in cert if c["holds"]] or [0.0]),
@@ -390,6 +393,7 @@ def test_trocr_base_f16_model_with_margins_is_string_exact(ctx):
         if x["diverged_at"] is None:
             assert e, i
     assert sum(held) >= 40, rep
+    assert sum(equal) >= 0.95 * len(crops), rep                  # measured: 80 of 80 lines token-equal
     assert len(strings) >= 3 and len(rep["lengths"]) >= 2, rep
     for r in ref:
         t = [int(v) for v in r[0]]

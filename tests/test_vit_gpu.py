@@ -43,30 +43,47 @@ def test_fp32_matches_reference_golden(ctx, tag):
     m.close()
 
 
-@pytest.mark.parametrize("stream", ["fp32_stream", "f16_stream"])
+STREAM_ERRORS = {}
+
+
+@pytest.mark.parametrize("stream", ["split_stream", "fp32_stream", "f16_stream"])
 @pytest.mark.parametrize("tag", ["small", "base"])
 def test_f16_close_to_reference_golden(ctx, tag, stream, monkeypatch):
-    """f16 mode against the reference's goldens.  f16_stream: the opt-in f16 residual stream (MARIE_HIP_RESIDUAL_F16, read when the
-    model is created — what the reference's .half() path has; measured +2.5 % pages/s and ~1.4x the f16 error of the default,
-    which keeps the stream in fp32) is held to the same bar."""
+    """f16 mode against the reference's goldens, one bar for the three ways the residual stream can be kept (chosen when the
+    model is created):
+    split_stream  (default) two f16 planes x = hi + lo (~22 significant bits); every LayerNorm in front of a GEMM is folded around
+                  that GEMM (hi is its operand, row statistics come out of the producing GEMM's epilogue): no LayerNorm pass;
+    fp32_stream   MARIE_HIP_NO_LN_FOLD=1: fp32 stream + LayerNorm passes (the default of rounds 1-2);
+    f16_stream    MARIE_HIP_RESIDUAL_F16=1: what the reference's .half() path has (~1.4x the f16 error of the other two)."""
+    import json
+
     from marie_icr_amd._lib import PREC_F16
     from marie_icr_amd.vit import VitModel, make_config
 
+    monkeypatch.delenv("MARIE_HIP_RESIDUAL_F16", raising=False)
+    monkeypatch.delenv("MARIE_HIP_NO_LN_FOLD", raising=False)
     if stream == "f16_stream":
         monkeypatch.setenv("MARIE_HIP_RESIDUAL_F16", "1")
-    else:
-        monkeypatch.delenv("MARIE_HIP_RESIDUAL_F16", raising=False)
+    elif stream == "fp32_stream":
+        monkeypatch.setenv("MARIE_HIP_NO_LN_FOLD", "1")
     g, st, imgs = _case(tag)
     m = VitModel(ctx, make_config(int(g["dim"]), int(g["depth"]), int(g["heads"]), g["taps"].tolist()), st, PREC_F16)
     out = m.forward_host(imgs, g["canvas_hw"])
     step = int(g["channel_step"])
+    rec = []
     for j, f in enumerate(out["fpn"]):
         ref = np.transpose(g[f"fpn{j}"], (0, 2, 3, 1))
         err = np.abs(f[..., ::step] - ref)
+        rec.append({"max_over_range": float(err.max() / np.abs(ref).max()), "mean_over_range": float(err.mean() / np.abs(ref).max())})
         # f16 operands through 12 residual blocks: 2 % of the activation range at worst, 0.3 % on average
         assert err.max() <= 0.02 * np.abs(ref).max() + 0.02, (j, err.max(), np.abs(ref).max())
         assert err.mean() <= 0.003 * np.abs(ref).max(), (j, err.mean())
     m.close()
+    STREAM_ERRORS[f"{tag}/{stream}"] = rec
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "vit_stream_errors.json"), "w") as fo:
+            json.dump(STREAM_ERRORS, fo, indent=1)
 
 
 def test_deit_variant_vs_oracle(ctx):

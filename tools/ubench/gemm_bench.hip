@@ -89,5 +89,67 @@ int main(int argc, char** argv) {
     printf("      %.0f tiles, %.1f rounds of 256, %.2f us per tile (%d slices)\n", tiles, rounds, ms * 1e3 / rounds, s.K / 64);
   }
   printf("layer (4 GEMMs)        %8.3f ms  %7.1f TFLOP/s\n", tot_ms, tot_fl / tot_ms * 1e-9);
+
+  // ---- one encoder layer as vit_api.hip launches it, both ways of keeping the residual stream (D = 768) ----
+  //   fp32 stream: q|k 768->1536, V^T (W_v as the row operand), proj -> fp32 + fp32 residual, fc1 + GELU, fc2 -> fp32 + fp32 residual
+  //   split stream: the same five with the LayerNorm-folded epilogues (EPI_LN_ROWS / EPI_LN_COLS / EPI_SPLIT)
+  {
+    const int D = 768;
+    float *X32, *vec;                 // fp32 stream; per-row / per-column vectors (rstd, mean * rstd, column sums, biases)
+    _Float16 *Xhi, *Xlo, *VT;
+    float* stats;
+    CK(hipMalloc((void**)&X32, (size_t)rows * D * 4)); CK(hipMalloc((void**)&Xhi, (size_t)rows * D * 2)); CK(hipMalloc((void**)&Xlo, (size_t)rows * D * 2));
+    CK(hipMalloc((void**)&VT, ((size_t)rows * D + 4096) * 2)); CK(hipMalloc((void**)&stats, (size_t)rows * (D / 64) * 8));
+    const size_t nvec = (size_t)(rows > 3072 ? rows : 3072) + 64;
+    CK(hipMalloc((void**)&vec, nvec * 4));
+    CK(hipMemset(X32, 0, (size_t)rows * D * 4));
+    std::vector<float> ones(nvec, 1.0f);
+    CK(hipMemcpy(vec, ones.data(), nvec * 4, hipMemcpyHostToDevice));
+    fill_kernel<<<1024, 256, 0, ctx.stream>>>(Xhi, (size_t)rows * D, 5u, 1.0f);
+    fill_kernel<<<1024, 256, 0, ctx.stream>>>(Xlo, (size_t)rows * D, 6u, 0.0005f);
+    struct G { const char* name; int split; ConvDesc d; double fl; };
+    std::vector<G> gs;
+    auto base = [&](const void* in, const void* w, long long M, int N, int K, void* out) {
+      ConvDesc d; d.in = in; d.w = w; d.out = out; d.B = 1; d.H = 1; d.W = (int)M; d.Cin = K; d.N = N; d.bias = bias; return d;
+    };
+    for (int split = 0; split < 2; ++split) {
+      ConvDesc qk = base(split ? (void*)Xhi : (void*)A, W, rows, 2 * D, D, C);
+      ConvDesc vt = base(W, split ? (void*)Xhi : (void*)A, D, rows, D, VT); vt.bias = nullptr;
+      ConvDesc pj = base(A, W, rows, D, D, split ? (void*)Xhi : (void*)X32);
+      ConvDesc f1 = base(split ? (void*)Xhi : (void*)A, W, rows, 4 * D, D, C); f1.relu = ACT_GELU;
+      ConvDesc f2 = base(A, W, rows, D, 4 * D, split ? (void*)Xhi : (void*)X32);
+      if (split) {
+        qk.epi = f1.epi = EPI_LN_ROWS; qk.ln_a = f1.ln_a = vec; qk.ln_b = f1.ln_b = vec; qk.ln_cs = f1.ln_cs = vec;
+        vt.epi = EPI_LN_COLS; vt.ln_a = vec; vt.ln_b = vec; vt.ln_cs = vec; vt.row_bias = vec;
+        for (ConvDesc* p : {&pj, &f2}) { p->epi = EPI_SPLIT; p->out2 = Xlo; p->res = Xhi; p->res2 = Xlo; p->stats = stats; p->stats_ld = rows; p->scale = vec; }
+      } else {
+        for (ConvDesc* p : {&pj, &f2}) { p->out_f32 = 1; p->res = X32; p->scale = vec; }
+      }
+      gs.push_back({split ? "split q|k" : "fp32  q|k", split, qk, 2.0 * rows * D * 2.0 * D});
+      gs.push_back({split ? "split V^T" : "fp32  V^T", split, vt, 2.0 * rows * D * (double)D});
+      gs.push_back({split ? "split proj" : "fp32  proj", split, pj, 2.0 * rows * D * (double)D});
+      gs.push_back({split ? "split fc1" : "fp32  fc1", split, f1, 2.0 * rows * D * 4.0 * D});
+      gs.push_back({split ? "split fc2" : "fp32  fc2", split, f2, 2.0 * rows * D * 4.0 * D});
+    }
+    std::vector<double> best(gs.size(), 1e30);
+    for (int round = 0; round < 3; ++round)          // interleaved rounds in one process
+      for (size_t k = 0; k < gs.size(); ++k) {
+        for (int w = 0; w < 1; ++w) if (mhip_launch_conv_igemm(&ctx, MHIP_PREC_F16, gs[k].d)) return 1;
+        CK(hipEventRecord(e0, ctx.stream));
+        for (int i = 0; i < iters; ++i) if (mhip_launch_conv_igemm(&ctx, MHIP_PREC_F16, gs[k].d)) return 1;
+        CK(hipEventRecord(e1, ctx.stream));
+        CK(hipStreamSynchronize(ctx.stream));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms / iters < best[k]) best[k] = ms / iters;
+      }
+    double t[2] = {0, 0}, f[2] = {0, 0};
+    for (size_t k = 0; k < gs.size(); ++k) {
+      printf("%-12s %8.3f ms  %7.1f TFLOP/s\n", gs[k].name, best[k], gs[k].fl / best[k] * 1e-9);
+      t[gs[k].split] += best[k]; f[gs[k].split] += gs[k].fl;
+    }
+    printf("encoder layer, fp32 stream  %8.3f ms  %7.1f TFLOP/s (+ two LayerNorm passes)\n", t[0], f[0] / t[0] * 1e-9);
+    printf("encoder layer, split stream %8.3f ms  %7.1f TFLOP/s\n", t[1], f[1] / t[1] * 1e-9);
+  }
   return 0;
 }
