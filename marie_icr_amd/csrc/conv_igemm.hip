@@ -74,11 +74,18 @@ struct Cfg {
 // about one fp32 ulp of (1 + erf) — branch-free: one v_rcp, one v_exp and five FMAs instead of ocml erff's two-branch
 // polynomial (the fc1 GEMM applies this to 3072 columns of every token).
 __device__ __forceinline__ float gelu_erf(float t) {
+  // every multiply-add is spelled out: the epilogue exists in several copies (bounds-checked, straight-line) and a tile's values
+  // must not depend on which copy wrote it — left to the compiler, the contraction of a * b + c may differ from copy to copy
   const float x = t * 0.70710678118654752f, ax = fabsf(x);
-  const float u = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
-  const float poly = ((((1.061405429f * u - 1.453152027f) * u + 1.421413741f) * u - 0.284496736f) * u + 0.254829592f) * u;
-  const float e = 1.f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-  return 0.5f * t * (1.f + copysignf(e, x));
+  const float u = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.f));
+  float poly = __builtin_fmaf(1.061405429f, u, -1.453152027f);
+  poly = __builtin_fmaf(poly, u, 1.421413741f);
+  poly = __builtin_fmaf(poly, u, -0.284496736f);
+  poly = __builtin_fmaf(poly, u, 0.254829592f);
+  poly = poly * u;
+  const float e = __builtin_fmaf(-poly, __builtin_amdgcn_exp2f((-1.4426950408889634f * ax) * ax), 1.f);
+  const float h = 0.5f * t;
+  return __builtin_fmaf(h, copysignf(e, x), h);
 }
 
 // sum over the 8 lanes of an aligned lane group without leaving the VALU (HIP's __shfl_xor is a ds_bpermute: an LDS-crossbar round
@@ -142,6 +149,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
     mt = L / p.ntiles;
   }
   const int m0 = mt * BM, n0 = nt * C::BN;
+  if (p.stagger > 0 && blockIdx.x < 256 && (blockIdx.x & 8)) {       // experiment: half of the first round starts late
+    for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+  }
 
   // ---- staging set-up: each thread moves BM/64 A chunks + BN/64 W chunks per slice ---------
   // a wave-instruction covers RPI rows; a thread's q-th chunk sits RPI*8 rows further down
@@ -487,9 +497,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (EPI == EPI_LN_ROWS) v[r] = acc[i][j][r] * lr_a[r] - lr_b[r] * lnc_b[j] + bi4[j];
-          else if (EPI == EPI_LN_COLS) v[r] = acc[i][j][r] * lnc_a[j] - lnc_b[j] * lr_a[r] + lr_b[r];
-          else v[r] = fmaxf(acc[i][j][r] * sc4[j] + bi4[j], lo);
+          if (EPI == EPI_LN_ROWS) v[r] = __builtin_fmaf(acc[i][j][r], lr_a[r], __builtin_fmaf(-lr_b[r], lnc_b[j], bi4[j]));
+          else if (EPI == EPI_LN_COLS) v[r] = __builtin_fmaf(acc[i][j][r], lnc_a[j], __builtin_fmaf(-lnc_b[j], lr_a[r], lr_b[r]));
+          else v[r] = fmaxf(__builtin_fmaf(acc[i][j][r], sc4[j], bi4[j]), lo);
         }
         if (POOL == POOL_2x2) {
           lds_put<float>(wst, SPW, fg, lc, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
@@ -531,7 +541,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
           const float mc = sm * (1.f / 64.f);
           float m2 = 0.f;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { const float d = f[k] - mc; m2 += d * d; }
+          for (int k = 0; k < 8; ++k) { const float d = f[k] - mc; m2 = __builtin_fmaf(d, d, m2); }
           m2 = sum8(m2);
           const int pi = i * NRES16 + t;
           if ((lane & 7) == (pi & 7)) { keep_s[pi >> 3] = sm; keep_q[pi >> 3] = m2; }
@@ -685,15 +695,149 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(IgemmArgs p) {
       }
     }
   };
+  // EPI_SPLIT on a tile that lies entirely inside the output (all but the last row of tiles of a GEMM): the same arithmetic as
+  // `body` as straight-line code — no bounds test, so no branch around any load or store, so the compiler counts its waits exactly
+  // (with a branch per request it fell back to vmcnt(0) in front of the first use) — and the two planes of the residual are
+  // requested SPLIT_AHEAD row-tiles before they are needed: the epilogue of a residual GEMM is bound by how many bytes a CU has in
+  // flight (one row-tile per wave = 32 KiB per CU against ~2 us of loaded HBM latency: 15 us of a 43 us proj tile).
+  auto split_fast = [&]() {
+    constexpr int AH = 3;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const size_t lane_off = (size_t)(m0 + wr * (MT * 16) + r8) * grow + (size_t)(n0 + wc * 64 + c8 * 8) * 2;
+    const char* rh = p.res + lane_off;
+    const char* rl = p.res2 + lane_off;
+    char* oh = p.out + lane_off;
+    char* ol = p.out2 + lane_off;
+    const size_t step8 = 8 * grow;
+    half8 qh[MT][2], ql[MT][2];
+    auto request = [&](int i) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        qh[i][t] = *(const half8*)(rh + (size_t)(i * 2 + t) * step8);
+        ql[i][t] = *(const half8*)(rl + (size_t)(i * 2 + t) * step8);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < AH && i < MT; ++i) request(i);
+    constexpr int NPASS = MT * 2, NSET = (NPASS + 7) / 8;
+    float keep_s[NSET], keep_q[NSET];
+#pragma unroll
+    for (int k = 0; k < NSET; ++k) keep_s[k] = keep_q[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (i + AH < MT) request(i + AH);
+      char* wst = wst0 + (i & 1) * (16 * SPW);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds_put<float>(wst, SPW, fg * 4 + r, j * 16 + frow, fmaxf(__builtin_fmaf(acc[i][j][r], sc4[j], bi4[j]), lo));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      half8 hv[2], lv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = t * 8 + r8;
+        const float4v a0 = *(const float4v*)(wst + row * SPW + c8 * 32), a1 = *(const float4v*)(wst + row * SPW + c8 * 32 + 16);
+        float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += (float)qh[i][t][k] + (float)ql[i][t][k];
+        float sm = sum8(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7])));
+        const float mc = sm * (1.f / 64.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = f[k] - mc; m2 = __builtin_fmaf(d, d, m2); }
+        m2 = sum8(m2);
+        const int pi = i * 2 + t;
+        if ((lane & 7) == (pi & 7)) { keep_s[pi >> 3] = sm; keep_q[pi >> 3] = m2; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          hv[t][k] = (_Float16)f[k];
+          lv[t][k] = (_Float16)(f[k] - (float)hv[t][k]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (C::SMALL) {
+          *(half8*)(oh + (size_t)(i * 2 + t) * step8) = hv[t];
+          *(half8*)(ol + (size_t)(i * 2 + t) * step8) = lv[t];
+        } else {
+          __builtin_nontemporal_store(hv[t], (half8*)(oh + (size_t)(i * 2 + t) * step8));
+          __builtin_nontemporal_store(lv[t], (half8*)(ol + (size_t)(i * 2 + t) * step8));
+        }
+      }
+    }
+    const int c64 = (n0 + wc * 64) >> 6;
+#pragma unroll
+    for (int k = 0; k < NSET; ++k) {
+      const int pass = k * 8 + c8;
+      if (pass < NPASS) {
+        float* dst = p.stats + ((size_t)c64 * p.stats_ld + (size_t)(m0 + wr * (MT * 16) + pass * 8 + r8)) * 2;
+        dst[0] = keep_s[k];
+        dst[1] = keep_q[k];
+      }
+    }
+  };
+  // The same for the f16 outputs without a residual (q|k, V^T, fc1, every unpooled convolution into f16): `body` spends ~200
+  // instructions per row-tile and wave on ~70 of arithmetic — bounds tests, a branch per chunk, 64-bit address arithmetic per
+  // chunk, the row-period division — and both waves of a SIMD are in their epilogues together with the matrix cores idle.
+  auto f16_fast = [&](auto GELU_) {
+    constexpr bool GELU = decltype(GELU_)::value;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    char* o = p.out + (size_t)(m0 + wr * (MT * 16) + r8) * grow + (size_t)(n0 + wc * 64 + c8 * 8) * 2;
+    const size_t step8 = 8 * grow;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      char* wst = wst0 + (i & 1) * (16 * SPW);
+      float4v lr_a = (float4v){0.f, 0.f, 0.f, 0.f}, lr_b = (float4v){0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_LN_ROWS || EPI == EPI_LN_COLS) {
+        lr_a = *(const float4v*)(rvs + i * 16 + fg * 4);
+        lr_b = *(const float4v*)(rvs + MT * 16 + i * 16 + fg * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v;
+          if (EPI == EPI_LN_ROWS) v = __builtin_fmaf(acc[i][j][r], lr_a[r], __builtin_fmaf(-lr_b[r], lnc_b[j], bi4[j]));
+          else if (EPI == EPI_LN_COLS) v = __builtin_fmaf(acc[i][j][r], lnc_a[j], __builtin_fmaf(-lnc_b[j], lr_a[r], lr_b[r]));
+          else v = fmaxf(__builtin_fmaf(acc[i][j][r], sc4[j], bi4[j]), lo);
+          lds_put<float>(wst, SPW, fg * 4 + r, j * 16 + frow, v);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      half8 ov[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = t * 8 + r8;
+        const float4v a0 = *(const float4v*)(wst + row * SPW + c8 * 32), a1 = *(const float4v*)(wst + row * SPW + c8 * 32 + 16);
+        float f[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (GELU)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) f[k] = gelu_erf(f[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ov[t][k] = (_Float16)f[k];
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (C::SMALL) *(half8*)(o + (size_t)(i * 2 + t) * step8) = ov[t];
+        else __builtin_nontemporal_store(ov[t], (half8*)(o + (size_t)(i * 2 + t) * step8));
+      }
+    }
+  };
   typedef std::true_type Y;
   typedef std::false_type N_;
   const bool has_res = p.res != nullptr;
+  const bool full_tile = POOL == POOL_NONE && m0 + BM <= p.M && n0 + C::BN <= p.N && !p.row_period;
   if constexpr (EPI == EPI_SPLIT) {
-    body(N_{}, Y{}, N_{}, Y{});
+    if (full_tile) split_fast();
+    else body(N_{}, Y{}, N_{}, Y{});
   } else if constexpr (EPI == EPI_LN_ROWS) {
-    if (gelu) body(N_{}, N_{}, Y{}, Y{}); else body(N_{}, N_{}, N_{}, Y{});
+    if (full_tile) { if (gelu) f16_fast(Y{}); else f16_fast(N_{}); }
+    else if (gelu) body(N_{}, N_{}, Y{}, Y{}); else body(N_{}, N_{}, N_{}, Y{});
   } else if constexpr (EPI == EPI_LN_COLS) {
-    body(N_{}, N_{}, N_{}, Y{});
+    if (full_tile) f16_fast(N_{}); else body(N_{}, N_{}, N_{}, Y{});
+  } else if (POOL == POOL_NONE && vec && oe == 2 && !has_res && full_tile) {
+    if (gelu) f16_fast(Y{}); else f16_fast(N_{});
   } else if (!vec) {
     if (gelu) body(N_{}, N_{}, Y{}, N_{}); else body(N_{}, N_{}, N_{}, N_{});
   } else if (oe == 4) {
@@ -830,6 +974,8 @@ int mhip_launch_conv_igemm(mhip_ctx* ctx, int precision, const ConvDesc& d) {
     return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: bad output pitch %d", a.ldc);
   if ((a.res || a.ldc) && ((size_t)(a.ldc ? a.ldc : d.N) * (d.out_f32 ? 4 : esz)) % 16 != 0)
     return mhip_fail(ctx, MHIP_EINVAL, "conv_igemm: residual / pitched outputs need 16-byte aligned rows");
+  static const int stagger_env = getenv("MARIE_HIP_STAGGER") ? atoi(getenv("MARIE_HIP_STAGGER")) : 0;
+  a.stagger = stagger_env * (d.KH * d.KW * d.Cin / 64) / 16;      // in sixteenths of a slice count
   a.epi = d.epi;
   a.ln_a = d.ln_a; a.ln_b = d.ln_b; a.ln_cs = d.ln_cs; a.row_bias = d.row_bias;
   a.out2 = (char*)d.out2; a.res2 = (const char*)d.res2; a.stats = d.stats; a.stats_ld = d.stats_ld;

@@ -48,6 +48,7 @@ struct IgemmArgs {
   const float* row_bias;   // EPI_LN_COLS: bias per GEMM row m
   char* out2;          // EPI_SPLIT: the low plane of the output (out = high plane), same pitch
   const char* res2;    // EPI_SPLIT: the low plane of the residual
+  int stagger;         // experiment (MARIE_HIP_STAGGER): s_sleep units the odd workgroups of the first round wait before starting
   float* stats;        // EPI_SPLIT: per 64-column chunk c and output row r: (sum, centred sum of squares) at stats[(c*stats_ld + r)*2]
   int stats_ld;
 };

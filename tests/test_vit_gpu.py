@@ -86,6 +86,26 @@ def test_f16_close_to_reference_golden(ctx, tag, stream, monkeypatch):
             json.dump(STREAM_ERRORS, fo, indent=1)
 
 
+def test_f16_output_does_not_depend_on_the_batch(ctx):
+    """An image's feature maps are the same bits whatever else is in the batch: the GEMM epilogue exists in a bounds-checked and
+    a straight-line copy (tiles that lie entirely inside the output), the tile shape follows the row count, and every copy and
+    shape must produce the same values (multiply-adds are spelled out in conv_igemm.hip for this reason)."""
+    from marie_icr_amd._lib import PREC_F16
+    from marie_icr_amd.vit import VitModel, make_config
+
+    g, st, _ = _case("base")
+    imgs = make_image_u8(21, 9, int(g["image_hw"][0]), int(g["image_hw"][1]))
+    m = VitModel(ctx, make_config(int(g["dim"]), int(g["depth"]), int(g["heads"]), g["taps"].tolist()), st, PREC_F16)
+    alone = m.forward_host(imgs[:1], g["canvas_hw"])
+    three = m.forward_host(imgs[:3], g["canvas_hw"])
+    nine = m.forward_host(imgs, g["canvas_hw"])
+    m.close()
+    for a, b, c in zip(alone["fpn"], three["fpn"], nine["fpn"]):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[0], c[0])
+        np.testing.assert_array_equal(b[2], c[2])
+
+
 def test_deit_variant_vs_oracle(ctx):
     """TrOCR encoder flavour: no layer scale, full qkv bias, final norm, 24 x 24 position grid used at its own size,
     plus a key count (577) that is not a multiple of the 64-key tile (mask path)."""
