@@ -809,8 +809,11 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
         bp = make_box(fixed, refine)
         eng = MarieHipOcrEngine(box_processor=bp, default_ocr_processor=tp)
         eng.page_batch = min(P, args.engine_page_batch)    # several batches: the detector of batch k + 1 runs under the recognizer of batch k
+        if args.engine_first_batch > 0:
+            eng.first_batch = args.engine_first_batch
         # wall time spent inside the two processors (they run on two host threads, so the two can add up to more than the call)
         spent = {"detect_s": 0.0, "recognize_s": 0.0}
+        spans = []          # (what, pages, start, end) of every processor call: the timeline of the last extract()
 
         def timed(fn, key):
             def wrapper(*a, **k):
@@ -818,7 +821,9 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
                 try:
                     return fn(*a, **k)
                 finally:
-                    spent[key] += time.perf_counter() - t
+                    e = time.perf_counter()
+                    spent[key] += e - t
+                    spans.append((key[:-2], len(a[2]) if len(a) > 2 else 0, t, e))
             return wrapper
         bp.extract_bounding_boxes_batch = timed(bp.extract_bounding_boxes_batch, "detect_s")
         orig_rec = tp.recognize_pages
@@ -831,6 +836,8 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
         spent.update(detect_s=0.0, recognize_s=0.0)
         t0 = time.perf_counter()
         for _ in range(reps):
+            del spans[:]
+            tl0 = time.perf_counter()
             res = eng.extract(fr, PSMode.SPARSE, CoordinateFormat.XYXY)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -839,7 +846,8 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
         out[name] = {"value": reps * n_pages / dt, "unit": "pages/s", "pages_per_call": n_pages, "words_per_page": words,
                      "lines_per_page": sum(len(r["lines"]) for r in res) / len(res), "page_batch": eng.page_batch,
                      "s_per_call": dt / reps, "s_in_box_processor": spent["detect_s"] / reps,
-                     "s_in_ocr_processor": spent["recognize_s"] / reps}
+                     "s_in_ocr_processor": spent["recognize_s"] / reps,
+                     "timeline_ms": [[w, n, round((a - tl0) * 1e3, 1), round((b - tl0) * 1e3, 1)] for w, n, a, b in sorted(spans, key=lambda x: x[2])]}
     out["what"] = ("MarieHipOcrEngine.extract(frames) end to end, host numpy frames in (H2D inside), result dictionaries out; "
                    "fixed_lines: the detector runs in full but the generator's 40 line boxes go on (the headline's fixed work, "
                    "bbox_refinement=False); detector_driven: whatever the random-weight detector emits becomes a crop "
@@ -867,6 +875,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--engine-page-batch", type=int, default=32, help="pages per detector / recognizer batch of the engine_api leg")
+    ap.add_argument("--engine-first-batch", type=int, default=0, help="pages of the first batch of the engine_api leg (0 = the engine's default)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["dit_trocr", "craft_crnn", "pages", "crnn"], default="dit_trocr")

@@ -83,6 +83,16 @@ def box_iou(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     return inter / (area_a[:, None] + area_b[None, :] - inter)
 
 
+class _Done:
+    """A finished upload (the single-page path needs no helper thread)."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
+
+
 class BoxProcessorUlimDit:
     """Drop-in for marie/boxes/dit/ulim_dit_box_processor.py:358."""
 
@@ -128,6 +138,41 @@ class BoxProcessorUlimDit:
         import torch
 
         return torch.from_numpy(np.ascontiguousarray(image)).cuda()
+
+    def _upload_all(self, images):
+        """Host pages -> HBM on a helper thread and a copy stream of its own, in the order given; returns one future per page whose
+        result is the device page, already ordered behind the caller's current stream.  A 2550 x 3300 page is 25 MB of pageable
+        memory (the reference's contract: numpy frames): copied up front, one after the other, the 64 pages of a call cost as much
+        wall time as their detector forwards — now page k + 1 crosses PCIe while the detector works on page k."""
+        import concurrent.futures
+        import torch
+
+        if len(images) <= 1:
+            return [_Done(self._upload(im)) for im in images]
+        copy_stream = torch.cuda.Stream()
+        user_stream = torch.cuda.current_stream()
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="marie-h2d")
+
+        def one(im):
+            with torch.cuda.stream(copy_stream):
+                t = torch.from_numpy(np.ascontiguousarray(im)).cuda()      # pageable source: blocks this thread only
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return t, ev
+
+        class _Page:
+            def __init__(self, fut):
+                self.fut = fut
+
+            def result(self):
+                t, ev = self.fut.result()
+                user_stream.wait_event(ev)
+                t.record_stream(user_stream)
+                return t
+
+        futs = [_Page(pool.submit(one, im)) for im in images]
+        pool.shutdown(wait=False)
+        return futs
 
     def _blackout(self, page_dev, boxes_xyxy) -> bool:
         b = np.ascontiguousarray(np.asarray(boxes_xyxy, np.float32).reshape(-1, 4).astype(np.int32))   # int(x): truncation
@@ -199,11 +244,25 @@ class BoxProcessorUlimDit:
                 framed, coord = resize_image(image, (self.min_size_test[0], self.min_size_test[1]), keep_max_size=True,
                                              ctx=self.ctx)
                 adj_x, adj_y = coord[0], coord[1]
-            dev = self._upload(framed)
-            # the refinement image: boxes found so far are painted white on it; the pristine copy stays for the fragments
-            work = dev.clone() if steps > 1 else dev
-            pages.append({"image": framed, "adj": (adj_x, adj_y), "dev": dev if framed is image else None, "pristine": dev, "work": work,
+            pages.append({"image": framed, "adj": (adj_x, adj_y), "unframed": framed is image,
                           "bboxes": [], "classes": [], "scores": [], "active": True})
+        # pages go to the device in the order the first pass takes them (grouped by shape), under the detector forwards
+        first: Dict[Tuple[int, ...], list] = {}
+        for pg in pages:
+            first.setdefault(tuple(pg["image"].shape), []).append(pg)
+        in_order = [pg for group in first.values() for pg in group]
+        for pg, fut in zip(in_order, self._upload_all([pg["image"] for pg in in_order])):
+            pg["upload"] = fut
+
+        def on_device(pg):
+            if "pristine" not in pg:
+                dev = pg.pop("upload").result()
+                pg["pristine"] = dev
+                pg["dev"] = dev if pg["unframed"] else None
+                # the refinement image: boxes found so far are painted white on it; the pristine copy stays for the fragments
+                pg["work"] = dev.clone() if steps > 1 else dev
+            return pg["work"]
+
         for i in range(steps):
             groups: Dict[Tuple[int, ...], list] = {}
             for pg in pages:
@@ -211,8 +270,11 @@ class BoxProcessorUlimDit:
                     groups.setdefault(tuple(pg["image"].shape), []).append(pg)
             if not groups:
                 break
-            for shape, group in groups.items():
-                dets = self._detect_batch([pg["work"] for pg in group], shape)
+            # det_batch pages per detector call: a call starts as soon as ITS pages have arrived (a page's boxes do not depend on
+            # what shares its forward)
+            nb = max(1, int(self.det_batch))
+            for shape, group in [(sh, whole[s0:s0 + nb]) for sh, whole in groups.items() for s0 in range(0, len(whole), nb)]:
+                dets = self._detect_batch([on_device(pg) for pg in group], shape)
                 for pg, (boxes, scores) in zip(group, dets):
                     bboxes_, classes_, scores_ = self._post_step(boxes, scores, shape, *pg["adj"])
                     # a single pass never looks at the whitened page again: the blackout is skipped (output-invariant)
@@ -274,7 +336,8 @@ class BoxProcessorUlimDit:
                                                  bbox_refinement)[0]
 
     def extract_bounding_boxes_batch(self, _id, key, imgs, psm=PSMode.SPARSE, bbox_optimization: Optional[bool] = False,
-                                     bbox_context_aware: Optional[bool] = True, bbox_refinement: Optional[bool] = None):
+                                     bbox_context_aware: Optional[bool] = True, bbox_refinement: Optional[bool] = None,
+                                     copy_fragments: bool = True):
         """``extract_bounding_boxes`` (ulim_dit_box_processor.py:676-832) for a list of pages with the detector batched over
         them; one 5-tuple per page, identical to what the per-page call returns.  ``fragments`` is a ``FragmentList``: numpy
         windows of the ORIGINAL image as in the reference, plus — when the page sits in HBM unframed — the device window each
@@ -327,8 +390,11 @@ class BoxProcessorUlimDit:
                 fragments = [fragments[i] for i in ind]
                 windows = [windows[i] for i in ind]
             usable = dev is not None and img.ndim == 3 and all(f.size > 0 for f in fragments)
-            fragments = FragmentList([np.array(f, dtype=np.uint8) for f in fragments], windows if usable else None,
-                                     [dev] if usable else ())
+            # the reference returns copies (ulim_dit_box_processor.py:805); a caller that reads the device windows and drops the
+            # list before the frames change (the engine's batched path) asks for views: the 40 line copies of a page cost 1.2 ms
+            if copy_fragments or not usable:
+                fragments = [np.array(f, dtype=np.uint8) for f in fragments]
+            fragments = FragmentList(fragments, windows if usable else None, [dev] if usable else ())
             prediction_result = {"bboxes": bboxes, "polys": bboxes, "scores": scores, "heatmap": None}
             results.append((rect_from_poly, fragments, rect_line_numbers, prediction_result, lines_bboxes))
         return results

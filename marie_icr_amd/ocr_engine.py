@@ -179,6 +179,7 @@ class OcrEngine:
         result["meta"]["format"] = coordinate_format.name.lower()
         return result
 
+    phase_align = False  # see _fullpage_batched
     page_batch = 32      # pages per detector / recognizer batch of the batched full-page path
     first_batch = 8      # pages of the first batch when batches overlap: nothing hides the first detector batch, so it is short
 
@@ -202,8 +203,14 @@ class OcrEngine:
         chunks = [list(range(s, min(len(frames), e))) for s, e in zip(starts, starts[1:] + [len(frames)])]
         overlap = overlap and len(chunks) > 1
 
+        import inspect
+
+        # fragments as views of the frames (read on the device, dropped before this call returns) where the processor offers it
+        views = ({"copy_fragments": False}
+                 if "copy_fragments" in inspect.signature(box_processor.extract_bounding_boxes_batch).parameters else {})
+
         def detect(idx):
-            return box_processor.extract_bounding_boxes_batch(queue_id, checksum, [frames[i] for i in idx], pms_mode)
+            return box_processor.extract_bounding_boxes_batch(queue_id, checksum, [frames[i] for i in idx], pms_mode, **views)
 
         def recognize(idx, found):
             pages = [(frames[i], f[0], f[1], f[2]) for i, f in zip(idx, found)]
@@ -217,7 +224,10 @@ class OcrEngine:
             return results
         q: "queue.Queue" = queue.Queue(maxsize=2)
         stop = threading.Event()
-        gate = getattr(icr_processor, "decode_gate", None)
+        # the phase gate (detector forwards of batch k + 1 held back until the recognizer of batch k decodes) is off by default here:
+        # measured on 64-page calls it costs 3 % (the detector starts later and still shares the GPU; profiles/r03), where the
+        # steady-state loop of bench.py gains 0.6 % from it
+        gate = getattr(icr_processor, "decode_gate", None) if getattr(self, "phase_align", False) else None
         targets: "queue.Queue" = queue.Queue()        # consumer -> producer: the gate signal that opens the next detector batch
         # processors without a device (the CPU stand-ins of the plumbing tests) overlap as plain host threads
         on_gpu = torch.cuda.is_available()
