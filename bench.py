@@ -811,6 +811,10 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
         eng.page_batch = min(P, args.engine_page_batch)    # several batches: the detector of batch k + 1 runs under the recognizer of batch k
         if args.engine_first_batch > 0:
             eng.first_batch = args.engine_first_batch
+        if os.environ.get("MARIE_ENGINE_STREAM_BATCH"):            # tuning aids (tools/r03_engine_sweep2.sh)
+            eng.stream_batch = int(os.environ["MARIE_ENGINE_STREAM_BATCH"])
+        if os.environ.get("MARIE_ENGINE_NO_STREAM"):
+            eng.stream_recognizer = False
         # wall time spent inside the two processors (they run on two host threads, so the two can add up to more than the call)
         spent = {"detect_s": 0.0, "recognize_s": 0.0}
         spans = []          # (what, pages, start, end) of every processor call: the timeline of the last extract()
@@ -823,11 +827,14 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
                 finally:
                     e = time.perf_counter()
                     spent[key] += e - t
-                    spans.append((key[:-2], len(a[2]) if len(a) > 2 else 0, t, e))
+                    spans.append((key[:-2], len(a[2]) if len(a) > 2 else (len(a[0]) if len(a) == 1 else 0), t, e))
             return wrapper
         bp.extract_bounding_boxes_batch = timed(bp.extract_bounding_boxes_batch, "detect_s")
         orig_rec = tp.recognize_pages
         tp.recognize_pages = timed(orig_rec, "recognize_s")
+        orig_add, orig_fin = tp.recognize_pages_add, tp.recognize_pages_finish       # the engine's streaming path: encode per batch,
+        tp.recognize_pages_add = timed(orig_add, "recognize_s")                      # one beam search at the end
+        tp.recognize_pages_finish = timed(orig_fin, "recognize_s")
         fr = frames[:n_pages]
         reps = 2 if fixed else 1
         if fixed:
@@ -841,7 +848,7 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
             res = eng.extract(fr, PSMode.SPARSE, CoordinateFormat.XYXY)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        tp.recognize_pages = orig_rec
+        tp.recognize_pages, tp.recognize_pages_add, tp.recognize_pages_finish = orig_rec, orig_add, orig_fin
         words = sum(len(r["words"]) for r in res) / len(res)
         out[name] = {"value": reps * n_pages / dt, "unit": "pages/s", "pages_per_call": n_pages, "words_per_page": words,
                      "lines_per_page": sum(len(r["lines"]) for r in res) / len(res), "page_batch": eng.page_batch,

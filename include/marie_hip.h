@@ -395,6 +395,15 @@ int mhip_trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int swap
 /* host crops; optional parity taps: enc_tokens_out fp32 [n][577][enc_dim], step0_logits_out fp32 [n][vocab]               */
 int mhip_trocr_generate_host(mhip_trocr* m, const uint8_t* crops_host, int n, int swap_rb, int32_t* tokens_out,
                              int32_t* lengths_out, float* scores_out, float* enc_tokens_out, float* step0_logits_out);
+/* The recognizer in two halves, for callers whose fragments arrive in batches (OcrEngine's batched path: page batches leave the
+ * detector one after the other, where the reference's loop calls its recognizer page by page, marie/ocr/ocr_engine.py:172-199):
+ * the image encoder (marie/models/unilm/trocr/deit.py:105-146) runs per batch of fragments, the beam search
+ * (generator.py:127-362) once over everything encoded since encode_begin — results as mhip_trocr_generate_fragments on the
+ * concatenated batches.  encode_begin(max_crops) reserves the token store (grow-only; more than max_crops may follow).       */
+int mhip_trocr_encode_begin(mhip_trocr* m, int max_crops);
+int mhip_trocr_encode_fragments(mhip_trocr* m, const uint8_t* base_dev, const mhip_crop_desc* descs_host, int n, int swap_rb);
+int mhip_trocr_encoded(mhip_trocr* m);      /* crops encoded since encode_begin                                               */
+int mhip_trocr_decode(mhip_trocr* m, int32_t* tokens_out, int32_t* lengths_out, float* scores_out);
 /* fragments of any size (3 channels) inside one device buffer -> Pillow bicubic to img x img -> generate                    */
 int mhip_trocr_generate_fragments(mhip_trocr* m, const uint8_t* base_dev, const mhip_crop_desc* descs_host, int n,
                                   int swap_rb, int32_t* tokens_out, int32_t* lengths_out, float* scores_out);

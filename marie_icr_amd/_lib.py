@@ -112,6 +112,10 @@ _SIGNATURES = (
     ("mhip_trocr_generate", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     ("mhip_trocr_generate_host", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("mhip_trocr_generate_fragments", _i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    ("mhip_trocr_encode_begin", _i, [_vp, _i]),
+    ("mhip_trocr_encode_fragments", _i, [_vp, _vp, _vp, _i, _i]),
+    ("mhip_trocr_encoded", _i, [_vp]),
+    ("mhip_trocr_decode", _i, [_vp, _vp, _vp, _vp]),
     ("mhip_trocr_generate_trace_host", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     ("mhip_cross_attention_host", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     ("mhip_max_page_size", _i, [_i, _i, _i, _i, C.c_double, C.POINTER(_i), C.POINTER(_i)]),

@@ -34,6 +34,10 @@ struct mhip_trocr {
   // "crops not finished yet" after every step, copied to pinned memory; the host reads it two steps late (never drains the stream)
   int* h_remaining = nullptr;
   hipEvent_t rem_ev[2] = {nullptr, nullptr};
+  // encoder tokens of the crops encoded since mhip_trocr_encode_begin (the encoder runs per batch of fragments as the page
+  // batches come out of the detector; the autoregressive decoder then runs once over all of them): [enc_cap * npad + 64][enc_dim] T
+  char* enc_store = nullptr;
+  int enc_cap = 0, enc_count = 0;
   size_t esz() const { return precision == MHIP_PREC_F16 ? 2 : 4; }
 };
 
@@ -119,6 +123,7 @@ extern "C" int mhip_trocr_destroy(mhip_trocr* m) {
   m->arena.release();
   if (m->frag_crops) (void)hipFree(m->frag_crops);
   if (m->frag_scratch) (void)hipFree(m->frag_scratch);
+  if (m->enc_store) (void)hipFree(m->enc_store);
   delete m;
   return MHIP_OK;
 }
@@ -267,6 +272,9 @@ struct TrocrTrace {          // host arrays [max_len + 1][n][2 * beam], filled f
   int steps;
 };
 
+static int trocr_decode(mhip_trocr* m, Carver& ws, const char* enc_tokens, const VitGeom& vg, int n, int32_t* tokens_out,
+                        int32_t* lengths_out, float* scores_out, float* step0_logits_host, TrocrTrace* trace);
+
 static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int swap_rb, int32_t* tokens_out,
                           int32_t* lengths_out, float* scores_out, float* enc_tokens_host, float* step0_logits_host,
                           TrocrTrace* trace = nullptr) {
@@ -275,14 +283,11 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
   if (n < 1) return mhip_fail(ctx, MHIP_EINVAL, "trocr: empty batch");
   MHIP_HIP(ctx, hipSetDevice(ctx->device));
   const mhip_trocr_config& c = m->cfg;
-  const int prec = m->precision, D = c.dec_dim, E = c.enc_dim, F = c.dec_ffn, beam = c.beam, L = c.dec_layers;
-  const int K2 = 2 * beam, ML = trocr_max_len(c), M = n * beam;
+  const int prec = m->precision, E = c.enc_dim;
   const size_t es = m->esz();
-  const int ldv = (c.vocab + 7) / 8 * 8;
   int rc = mhip_ensure_workspace(ctx, trocr_ws_bytes(m, n));
   if (rc) return rc;
   Carver ws(ctx->ws);
-  const Arena& a = m->arena;
   // ---- encoder --------------------------------------------------------------------------------------------------
   VitRun run;
   if ((rc = vit_encode(m->vit, ws, crops_dev, n, c.img_size, c.img_size, c.img_size, c.img_size, swap_rb, &run))) return rc;
@@ -295,6 +300,22 @@ static int trocr_generate(mhip_trocr* m, const uint8_t* crops_dev, int n, int sw
       MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
   }
+  return trocr_decode(m, ws, run.tokens, vg, n, tokens_out, lengths_out, scores_out, step0_logits_host, trace);
+}
+
+// The autoregressive part (TextRecognitionGenerator._generate, generator.py:127-362) over the encoder tokens of n crops:
+// enc_tokens T [n * vg.npad + 64 slack rows][enc_dim].
+static int trocr_decode(mhip_trocr* m, Carver& ws, const char* enc_tokens, const VitGeom& vg, int n, int32_t* tokens_out,
+                        int32_t* lengths_out, float* scores_out, float* step0_logits_host, TrocrTrace* trace) {
+  mhip_ctx* ctx = m->ctx;
+  const mhip_trocr_config& c = m->cfg;
+  const int prec = m->precision, D = c.dec_dim, E = c.enc_dim, F = c.dec_ffn, beam = c.beam, L = c.dec_layers;
+  const int K2 = 2 * beam, ML = trocr_max_len(c), M = n * beam;
+  const size_t es = m->esz();
+  const int ldv = (c.vocab + 7) / 8 * 8;
+  const Arena& a = m->arena;
+  int rc;
+  struct { const char* tokens; } run{enc_tokens};
   // ---- encoder keys / values of every decoder layer (static over the steps) -----------------------------------------
   const size_t cross_l = (size_t)n * vg.npad * D * es;
   char* ck = m->absorb ? nullptr : ws.take(L * cross_l);
@@ -489,6 +510,102 @@ extern "C" int mhip_trocr_generate_fragments(mhip_trocr* m, const uint8_t* base_
   }
   int rc = mhip_pil_resize_fragments(ctx, base_dev, descs_host, n, m->frag_crops, S, S, MHIP_PIL_BICUBIC, m->frag_scratch, m->frag_scratch_bytes);
   if (!rc) rc = trocr_generate(m, m->frag_crops, n, swap_rb, tokens_out, lengths_out, scores_out, nullptr, nullptr);
+  return rc;
+}
+
+// ---- the same recognizer in two halves: the image encoder per batch of fragments, the decoder once over all of them ----------
+// (OcrEngine's batched path: page batches leave the detector one after the other; their crops are encoded as they come — the
+// encoder's GEMMs are as efficient on 300 crops as on 3000 — while the decoder, whose 16 steps are latency-bound on small
+// batches (~5 ms per step whatever the batch), runs once.)
+static size_t trocr_decode_ws_bytes(const mhip_trocr* m, int n) {
+  VitGeom vg;
+  vit_geometry(m->vit, m->cfg.img_size, m->cfg.img_size, &vg);
+  return trocr_ws_bytes(m, n) - vit_workspace_bytes(m->vit, n, vg);
+}
+
+extern "C" int mhip_trocr_encode_begin(mhip_trocr* m, int max_crops) {
+  if (!m || max_crops < 0) return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  m->enc_count = 0;
+  if (max_crops > m->enc_cap) {
+    VitGeom vg;
+    vit_geometry(m->vit, m->cfg.img_size, m->cfg.img_size, &vg);
+    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->enc_store) (void)hipFree(m->enc_store);
+    m->enc_store = nullptr; m->enc_cap = 0;
+    MHIP_HIP(ctx, hipMalloc((void**)&m->enc_store, ((size_t)max_crops * vg.npad + 64) * m->cfg.enc_dim * m->esz()));
+    m->enc_cap = max_crops;
+  }
+  return MHIP_OK;
+}
+
+extern "C" int mhip_trocr_encoded(mhip_trocr* m) { return m ? m->enc_count : MHIP_EINVAL; }
+
+extern "C" int mhip_trocr_encode_fragments(mhip_trocr* m, const uint8_t* base_dev, const mhip_crop_desc* descs_host, int n,
+                                           int swap_rb) {
+  if (!m || !base_dev || !descs_host || n < 1) return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  if (!m->ready) return mhip_fail(ctx, MHIP_ESTATE, "trocr: weights not finalized");
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const mhip_trocr_config& c = m->cfg;
+  const int S = c.img_size;
+  const size_t es = m->esz();
+  VitGeom vg;
+  vit_geometry(m->vit, S, S, &vg);
+  if (m->enc_count + n > m->enc_cap) {      // grow, keeping what has been encoded
+    const int cap = std::max(m->enc_count + n, 2 * m->enc_cap);
+    char* bigger = nullptr;
+    MHIP_HIP(ctx, hipMalloc((void**)&bigger, ((size_t)cap * vg.npad + 64) * c.enc_dim * es));
+    if (m->enc_count) MHIP_HIP(ctx, hipMemcpyAsync(bigger, m->enc_store, (size_t)m->enc_count * vg.npad * c.enc_dim * es, hipMemcpyDeviceToDevice, ctx->stream));
+    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->enc_store) (void)hipFree(m->enc_store);
+    m->enc_store = bigger;
+    m->enc_cap = cap;
+  }
+  const size_t scratch = mhip_pil_resize_fragments_scratch(descs_host, n, S, S, MHIP_PIL_BICUBIC);
+  const size_t cb = (size_t)n * S * S * 3;
+  if (cb > m->frag_crops_bytes || scratch > m->frag_scratch_bytes) {
+    MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (cb > m->frag_crops_bytes) {
+      if (m->frag_crops) (void)hipFree(m->frag_crops);
+      m->frag_crops = nullptr; m->frag_crops_bytes = 0;
+      MHIP_HIP(ctx, hipMalloc((void**)&m->frag_crops, cb));
+      m->frag_crops_bytes = cb;
+    }
+    if (scratch > m->frag_scratch_bytes) {
+      if (m->frag_scratch) (void)hipFree(m->frag_scratch);
+      m->frag_scratch = nullptr; m->frag_scratch_bytes = 0;
+      MHIP_HIP(ctx, hipMalloc(&m->frag_scratch, scratch));
+      m->frag_scratch_bytes = scratch;
+    }
+  }
+  int rc = mhip_pil_resize_fragments(ctx, base_dev, descs_host, n, m->frag_crops, S, S, MHIP_PIL_BICUBIC, m->frag_scratch, m->frag_scratch_bytes);
+  if (rc) return rc;
+  if ((rc = mhip_ensure_workspace(ctx, vit_workspace_bytes(m->vit, n, vg) + (1 << 16)))) return rc;
+  Carver ws(ctx->ws);
+  VitRun run;
+  run.tokens_dst = m->enc_store + (size_t)m->enc_count * vg.npad * c.enc_dim * es;
+  if ((rc = vit_encode(m->vit, ws, m->frag_crops, n, S, S, S, S, swap_rb, &run))) return rc;
+  m->enc_count += n;
+  return MHIP_OK;
+}
+
+extern "C" int mhip_trocr_decode(mhip_trocr* m, int32_t* tokens_out, int32_t* lengths_out, float* scores_out) {
+  if (!m || !tokens_out || !lengths_out || !scores_out) return MHIP_EINVAL;
+  mhip_ctx* ctx = m->ctx;
+  if (m->enc_count < 1) return mhip_fail(ctx, MHIP_EINVAL, "trocr: nothing encoded since mhip_trocr_encode_begin");
+  MHIP_HIP(ctx, hipSetDevice(ctx->device));
+  const int n = m->enc_count;
+  VitGeom vg;
+  vit_geometry(m->vit, m->cfg.img_size, m->cfg.img_size, &vg);
+  // the 64 rows behind the last crop are read (masked) by its final key tiles: keep them finite
+  MHIP_HIP(ctx, hipMemsetAsync(m->enc_store + (size_t)n * vg.npad * m->cfg.enc_dim * m->esz(), 0, (size_t)64 * m->cfg.enc_dim * m->esz(), ctx->stream));
+  int rc = mhip_ensure_workspace(ctx, trocr_decode_ws_bytes(m, n) + (1 << 16));
+  if (rc) return rc;
+  Carver ws(ctx->ws);
+  rc = trocr_decode(m, ws, m->enc_store, vg, n, tokens_out, lengths_out, scores_out, nullptr, nullptr);
+  m->enc_count = 0;
   return rc;
 }
 

@@ -447,8 +447,12 @@ int vit_encode(mhip_vit* m, Carver& ws, const uint8_t* imgs, int B, int th, int 
   if (c.final_norm) {
     // + 64 finite rows: the decoder's encoder-attention walks every image's tokens in 32-row tiles and so reads (masked) rows
     // past the last image
-    run->tokens = ws.take((R + 64) * D * es);
-    MHIP_HIP(ctx, hipMemsetAsync(run->tokens + R * D * es, 0, (size_t)64 * D * es, ctx->stream));
+    if (run->tokens_dst) {
+      run->tokens = run->tokens_dst;
+    } else {
+      run->tokens = ws.take((R + 64) * D * es);
+      MHIP_HIP(ctx, hipMemsetAsync(run->tokens + R * D * es, 0, (size_t)64 * D * es, ctx->stream));
+    }
     if ((rc = mhip_launch_layernorm(ctx, prec, x, a.d<float>("norm_g"), a.d<float>("norm_b"), run->tokens, (int)R, D, c.ln_eps, x16 || fold, xlo))) return rc;
   }
   (void)tap_at;

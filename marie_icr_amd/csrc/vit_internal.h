@@ -34,6 +34,7 @@ struct VitRun {
   void* x_lo = nullptr;       // split stream: the low plane
   char* tap[4] = {nullptr};   // T [B*np][D] patch tokens after blocks cfg.taps[j]
   char* tokens = nullptr;     // T [B*npad][D] after the final norm (final_norm models)
+  char* tokens_dst = nullptr; // set by the caller: the final norm writes here instead of into the workspace (its own slack rows)
 };
 
 struct VitFpnOut {

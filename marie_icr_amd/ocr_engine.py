@@ -181,6 +181,8 @@ class OcrEngine:
 
     phase_align = False  # see _fullpage_batched
     page_batch = 32      # pages per detector / recognizer batch of the batched full-page path
+    stream_recognizer = True
+    stream_batch = 8     # pages per detector batch when the recognizer takes its pages in batches and finishes them together
     first_batch = 8      # pages of the first batch when batches overlap: nothing hides the first detector batch, so it is short
 
     def _fullpage_batched(self, frames, queue_id, checksum, pms_mode, coordinate_format, box_processor, icr_processor):
@@ -196,7 +198,11 @@ class OcrEngine:
 
         import torch
 
-        B = max(1, int(self.page_batch))
+        # a recognizer that encodes page batches as they arrive and searches once over all of them (TrOcrProcessor): the detector
+        # hands over small batches, nothing is recognized twice, and the beam search runs at the size of the whole call
+        streaming = self.stream_recognizer and all(hasattr(icr_processor, a) for a in
+                                                   ("recognize_pages_begin", "recognize_pages_add", "recognize_pages_finish"))
+        B = max(1, int(self.stream_batch if streaming else self.page_batch))
         overlap = len(frames) > 1 and getattr(box_processor, "ctx", None) is not getattr(icr_processor, "ctx", None)
         head = min(B, max(1, int(self.first_batch))) if overlap and len(frames) > B // 2 else B
         starts = [0] + list(range(head, len(frames), B))
@@ -212,15 +218,30 @@ class OcrEngine:
         def detect(idx):
             return box_processor.extract_bounding_boxes_batch(queue_id, checksum, [frames[i] for i in idx], pms_mode, **views)
 
+        handed = []          # streaming: (page index, detector output) of every page given to the recognizer so far
+
         def recognize(idx, found):
             pages = [(frames[i], f[0], f[1], f[2]) for i, f in zip(idx, found)]
+            if streaming:
+                icr_processor.recognize_pages_add(pages)
+                handed.extend(zip(idx, found))
+                return []
             recs = icr_processor.recognize_pages(queue_id, checksum, pages)
             return [self._finish_page(r, i, f[2], f[4], coordinate_format) for i, f, (r, _) in zip(idx, found, recs)]
 
+        def finish():
+            if not streaming:
+                return []
+            recs = icr_processor.recognize_pages_finish()
+            return [self._finish_page(r, i, f[2], f[4], coordinate_format) for (i, f), (r, _) in zip(handed, recs)]
+
         results: List[Dict] = []
+        if streaming:
+            icr_processor.recognize_pages_begin(len(frames))
         if not overlap:
             for idx in chunks:
                 results.extend(recognize(idx, detect(idx)))
+            results.extend(finish())
             return results
         q: "queue.Queue" = queue.Queue(maxsize=2)
         stop = threading.Event()
@@ -278,6 +299,7 @@ class OcrEngine:
                 if gate is not None:
                     targets.put(gate.count() + 1)       # the first decode phase of this batch's recognizer call
                 results.extend(recognize(*item))
+            results.extend(finish())
         finally:
             # whatever ended the loop (a recognizer error included): the producer must not stay blocked on the queue or the
             # gate holding device pages, and its stream must leave the detector's context
