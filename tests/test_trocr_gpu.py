@@ -98,6 +98,55 @@ def test_f16_and_processor_surface(ctx, case):
     assert same >= 3
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_encoder_per_batch_decoder_once_equals_one_call(ctx, case, precision):
+    """The recognizer in two halves (mhip_trocr_encode_begin / encode_fragments / decode, the engine's batched path): fragments
+    encoded in ragged batches — host fragments and windows of a device page mixed, the token store growing past its reservation —
+    and searched once give the hypotheses of ``recognize_from_fragments`` on the concatenation, bit for bit; pages without boxes
+    pass through; a second call on the same processor starts from an empty store; ``decode_batch`` splits the search."""
+    import torch
+
+    from marie_icr_amd.fragments import FragmentList
+    from marie_icr_amd.trocr import TrOcrProcessor
+
+    st = case[0]
+    rng = np.random.default_rng(17)
+    page = rng.integers(0, 256, size=(300, 700, 3)).astype(np.uint8)
+    dev = torch.from_numpy(page).cuda()
+    boxes = [(10, 20, 300, 40), (5, 100, 650, 33), (400, 200, 120, 60), (0, 0, 700, 25), (350, 150, 200, 18)]
+
+    def windows(sel):
+        fr = [page[y:y + h, x:x + w] for x, y, w, h in sel]
+        win = [(dev.data_ptr() + (y * 700 + x) * 3, h, w, 700 * 3, 3) for x, y, w, h in sel]
+        return FragmentList([np.array(f) for f in fr], win, [dev])
+
+    host = [rng.integers(0, 256, size=(int(h), int(w), 3)).astype(np.uint8) for h, w in ((40, 130), (25, 300), (60, 61), (33, 512))]
+    p = TrOcrProcessor(state=st, config=_cfg(ctx), precision=precision, ctx=ctx)
+    batches = [windows(boxes[:2]), FragmentList(host[:3]), windows(boxes[2:]), FragmentList(host[3:])]
+    flat = [f for b in batches for f in b]
+    ref = p.recognize_from_fragments(FragmentList(flat))
+    shape = page.shape
+    for decode_batch in (4096, 4):
+        p.decode_batch = decode_batch
+        p.recognize_pages_begin(5)
+        p.recognize_pages_add([(page, [[0, 0, 1, 1]] * len(batches[0]), batches[0], [1] * len(batches[0]))])
+        p.recognize_pages_add([(page, [], [], []),                                              # a blank page in the middle
+                               (page, [[0, 0, 1, 1]] * len(batches[1]), batches[1], [1] * len(batches[1]))])
+        p.recognize_pages_add([(page, [[0, 0, 1, 1]] * len(b), b, list(range(1, len(b) + 1))) for b in batches[2:]])
+        out = p.recognize_pages_finish()
+        assert len(out) == 5
+        got = [(w["text"], w["confidence"]) for res, _ in out for w in sorted(res["words"], key=lambda w: w["id"])]
+        assert out[1][0]["words"] == [] and out[1][0]["meta"]["imageSize"] == {"width": shape[1], "height": shape[0]}
+        want = [(r["text"], round(r["confidence"], 3)) for r in ref]
+        assert sorted(got) == sorted(want)
+        # per page: the page's own fragments, in order
+        k = 0
+        for j, b in zip((0, 2, 3, 4), batches):
+            words = sorted(out[j][0]["words"], key=lambda w: w["id"])
+            assert [w["text"] for w in words] == [r["text"] for r in ref[k:k + len(b)]]
+            k += len(b)
+
+
 def test_single_crop_and_extreme_fragments(ctx, case):
     """n = 1; 1-pixel-high, 1-pixel-wide and very wide fragments (Pillow-exact resize to 384 x 384 before the encoder)."""
     from marie_icr_amd.trocr import TrOcrProcessor
