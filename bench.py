@@ -264,9 +264,10 @@ def cpu_baseline_dit_trocr(dit_state, trocr_state, trocr_dims, decode_len, n_lin
 
 
 def _pmc_traffic(config):
-    """profiles/r02/pmc_traffic.json (rocprofv3 --pmc passes folded by tools/pmc_traffic.py) if it was taken on `config`."""
-    for rnd in ("r02", "r01"):
-        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json" if rnd == "r02" else "p_pmc_traffic.json")
+    """profiles/rNN/pmc_traffic.json (rocprofv3 --pmc passes folded by tools/pmc_traffic.py), newest round first, if it was taken
+    on `config`."""
+    for rnd in ("r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "p_pmc_traffic.json" if rnd == "r01" else "pmc_traffic.json")
         try:
             with open(path) as f:
                 d = json.load(f)
@@ -589,7 +590,7 @@ def run_dit_trocr(args, torch, dist, rank, local_rank, world, prec):
             "algorithmic_gflop_per_step": k["flops"] / 1e9, "algorithmic_gflop_per_launch": k["flops"] / 1e9 / max(k["launches"], 1),
             "measured": "HIP events on the launch streams around every conv_igemm launch of one more step run exactly as the "
                         "timed steps (detector and recognizer concurrently on two streams: in situ); FLOPs = 2*MAC of every "
-                        "launch (mhip_profile_flops).  profiles/r02/*_kernel_stats.csv is rocprofv3 --kernel-trace --stats of "
+                        "launch (mhip_profile_flops).  profiles/r03/c_*_kernel_stats.csv is rocprofv3 --kernel-trace --stats of "
                         "this command: sum its conv_igemm_kernel + conv3x3_patch_kernel rows",
             "isolated": {"achieved": tf(ki), "frac": tf(ki) / peak, "avg_launch_ms": ki["total_ms"] / max(ki["launches"], 1),
                          "measured": "same step, detector then recognizer alone (nothing else on the GPU); rocprofv3 of "

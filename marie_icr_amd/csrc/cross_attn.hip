@@ -35,9 +35,12 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
+#ifndef CA_E_AUX
+#define CA_E_AUX 2      // cache policy of the encoder-token stream: non-temporal (read once per launch; -3 % on the kernel, tools/ubench/hbm_read.hip: 6.2 -> 7.0 TB/s on the bare stream)
+#endif
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, CA_E_AUX);
 }
 __device__ __forceinline__ half4v lds_tr16(const char* p) {
   fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p);
@@ -80,9 +83,14 @@ constexpr int cross_slots(int ed, int w) {
 // it every ds_read_b64_tr_b16 that follows a global_load_lds gets an s_waitcnt vmcnt(0) in front (the transposed-read intrinsic
 // carries no alias information), i.e. the whole ring drains before the second product — measured 306 us per launch against
 // 244 us for the DMA stream alone.
-template <int ED, int W, int NPW, int NI>
+// FEED (compile time: the tile loop is split into the tiles that refill the ring and the last DEPTH that do not): with the
+// refill behind a run-time test every k-step was a basic block of its own — two LDS reads, a wait for exactly those two, two
+// MFMAs — i.e. a full LDS latency in front of every MFMA pair, twelve times per product (round 3: ~6000 cycles per tile measured
+// against ~2000 of stream at the rate a bare LDS-DMA ring reaches on this chip, tools/ubench/hbm_read.hip).  Straight-line, the
+// fragment reads of a product run AHEAD k-steps in front of the MFMAs that consume them.
+template <int ED, int W, int NPW, int NI, bool FEED>
 __device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __restrict__ feed_dst, float4v* __restrict__ xb,
-                                           const char* __restrict__ feed_src, bool feed, const int (&dma_off)[NPW],
+                                           const char* __restrict__ feed_src, const int (&dma_off)[NPW],
                                            const int (&a_off)[4], const int (&t_off)[8], const half8v (&qf)[ED / 64],
                                            float4v (&acc)[ED / 32], float& mref, float& lsum, int t, int n_keys, int wave, int lane) {
   constexpr int NW = 2 * W, ROWB = ED * 2, KS = ED / 64, MT = ED / 32;
@@ -90,24 +98,38 @@ __device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __
     // ---- partial S^T[32 keys][16 heads] = E_tile[:, half] Qt[:, half]^T
     float4v s[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
     constexpr int EVERY = (KS / NPW) > 0 ? (KS / NPW) : 1;
+    constexpr int AHEAD = KS < 4 ? KS : 4;
+    half8v a0[KS], a1[KS];
+#pragma unroll
+    for (int ks = 0; ks < AHEAD; ++ks) {
+      a0[ks] = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2));
+      a1[ks] = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2) + 16 * ROWB);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the scheduler sinks such reads back to their use (fewer live registers) unless fenced
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+      if (ks + AHEAD < KS) {
+        a0[ks + AHEAD] = *(const half8v*)(sb + a_off[(ks + AHEAD) & 3] + 256 * ((ks + AHEAD) >> 2));
+        a1[ks + AHEAD] = *(const half8v*)(sb + a_off[(ks + AHEAD) & 3] + 256 * ((ks + AHEAD) >> 2) + 16 * ROWB);
+      }
       // the DMA instructions of the tile that refills the slot freed at this tile's barrier go out now, as early as they may,
       // one per k-step (not in one burst: the CU's vector-memory queue drains a 1 KiB instruction every ~33 cycles and a wave
       // that issues 8 back to back waits in it with its LDS reads and MFMAs behind it)
-      if (ks % EVERY == 0 && ks / EVERY < NPW) {
+      if (FEED && ks % EVERY == 0 && ks / EVERY < NPW) {
         const int j = ks / EVERY, i = wave + j * NW;
-        if (feed && (NI % NW == 0 || i < NI)) glds16(feed_src + dma_off[j], feed_dst + i * 1024);
+        if (NI % NW == 0 || i < NI) glds16(feed_src + dma_off[j], feed_dst + i * 1024);
       }
-      const half8v a0 = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2));
-      const half8v a1 = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2) + 16 * ROWB);
-      s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, qf[ks], s[0], 0, 0, 0);
-      s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, qf[ks], s[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);    // reads of k-step ks + AHEAD | MFMAs of k-step ks: the order stays
+      s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ks], qf[ks], s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], qf[ks], s[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (FEED) {
 #pragma unroll
-    for (int j = (KS + EVERY - 1) / EVERY; j < NPW; ++j) {       // more DMA instructions than k-steps (narrow encoders)
-      const int i = wave + j * NW;
-      if (feed && (NI % NW == 0 || i < NI)) glds16(feed_src + dma_off[j], feed_dst + i * 1024);
+      for (int j = (KS + EVERY - 1) / EVERY; j < NPW; ++j) {       // more DMA instructions than k-steps (narrow encoders)
+        const int i = wave + j * NW;
+        if (NI % NW == 0 || i < NI) glds16(feed_src + dma_off[j], feed_dst + i * 1024);
+      }
     }
     // the other half's partial sums (same lane layout)
     xb[(wave * 2 + 0) * 64 + lane] = s[0];
@@ -147,12 +169,24 @@ __device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __
         pf[mt * 4 + e] = (_Float16)pe;
       }
     // ---- Ct^T[half of ED][16 heads] += E_tile[:, half]^T P^T
+    constexpr int TAHEAD = MT < 6 ? MT : 6;
+    half4v tlo[MT], thi[MT];
+#pragma unroll
+    for (int mt = 0; mt < TAHEAD; ++mt) {
+      tlo[mt] = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3));
+      thi[mt] = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3) + 16 * ROWB);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const half4v lo = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3));
-      const half4v hi = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3) + 16 * ROWB);
-      const half8v a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      if (mt + TAHEAD < MT) {
+        tlo[mt + TAHEAD] = lds_tr16(sb + t_off[(mt + TAHEAD) & 7] + 256 * ((mt + TAHEAD) >> 3));
+        thi[mt + TAHEAD] = lds_tr16(sb + t_off[(mt + TAHEAD) & 7] + 256 * ((mt + TAHEAD) >> 3) + 16 * ROWB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const half8v a = __builtin_shufflevector(tlo[mt], thi[mt], 0, 1, 2, 3, 4, 5, 6, 7);
       acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf, acc[mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -238,19 +272,28 @@ __global__ __launch_bounds__(128 * W) void cross_attn_kernel(CrossArgs p) {
   for (int i = 0; i < DEPTH; ++i)
     if (i < ntiles) issue(i, i);
   int slot = 0;
-  for (int t = 0; t < ntiles; ++t) {
+  // the tiles that refill the ring behind them: after each, DEPTH - 1 younger tiles are in flight
+  const int nfeed = ntiles > DEPTH ? ntiles - DEPTH : 0;
+  for (int t = 0; t < nfeed; ++t) {
     // tile t has landed once at most the DMA instructions of the tiles issued after it are outstanding
+    if (short_wave) wait_vm<(NPW - 1) * (DEPTH - 1)>();
+    else wait_vm<NPW * (DEPTH - 1)>();
+    __builtin_amdgcn_s_barrier();
+    // tile t + DEPTH goes into the slot tile t - 1 occupied (every wave is past its last read of it); cross_tile issues its DMA
+    // instructions between the MFMAs of the first product
+    const char* feed_src = Ec + (size_t)(t + DEPTH) * p.tile_stride;
+    char* feed_dst = smem + (slot == 0 ? NS - 1 : slot - 1) * TILE_B;
+    cross_tile<ED, W, NPW, NI, true>(smem + slot * TILE_B, feed_dst, xbuf, feed_src, dma_off, a_off, t_off, qf, acc, mref, lsum, t,
+                                     p.n_keys, wave, lane);
+    slot = (slot == NS - 1) ? 0 : slot + 1;
+  }
+  for (int t = nfeed; t < ntiles; ++t) {
     const int after = min(DEPTH - 1, ntiles - 1 - t);     // tiles issued after tile t
     if (short_wave) wait_vm_dyn<NPW - 1, DEPTH - 1>(after);
     else wait_vm_dyn<NPW, DEPTH - 1>(after);
     __builtin_amdgcn_s_barrier();
-    // tile t + DEPTH goes into the slot tile t - 1 occupied (every wave is past its last read of it); cross_tile issues its DMA
-    // instructions between the MFMAs of the first product
-    const bool feed = t + DEPTH < ntiles;
-    const char* feed_src = Ec + (size_t)(t + DEPTH) * p.tile_stride;
-    char* feed_dst = smem + (slot == 0 ? NS - 1 : slot - 1) * TILE_B;
-    cross_tile<ED, W, NPW, NI>(smem + slot * TILE_B, feed_dst, xbuf, feed_src, feed, dma_off, a_off, t_off, qf, acc, mref, lsum, t,
-                               p.n_keys, wave, lane);
+    cross_tile<ED, W, NPW, NI, false>(smem + slot * TILE_B, smem, xbuf, Ec, dma_off, a_off, t_off, qf, acc, mref, lsum, t, p.n_keys,
+                                      wave, lane);
     slot = (slot == NS - 1) ? 0 : slot + 1;
   }
   lsum += __shfl_xor(lsum, 16);

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/prof
 for mode in default serial; do
   extra=""; [ "$mode" = serial ] && extra="--serial"
   rm -rf /tmp/prof_$mode
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-mixed-dpi --host-steps 0 --no-kernel-timing $extra > gpurun_out/prof/${mode}_bench.json 2> gpurun_out/prof/${mode}_bench.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-mixed-dpi --host-steps 0 --no-kernel-timing --stream-pages 0 $extra > gpurun_out/prof/${mode}_bench.json 2> gpurun_out/prof/${mode}_bench.err
   echo "$mode rc=$?"
   cp $(find /tmp/prof_$mode -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${mode}_kernel_stats.csv
 done

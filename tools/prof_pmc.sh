@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-mixed-dpi --host-steps 0 --no-kernel-timing > gpurun_out/prof/pmc_$c.json 2> gpurun_out/prof/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-mixed-dpi --host-steps 0 --no-kernel-timing --stream-pages 0 > gpurun_out/prof/pmc_$c.json 2> gpurun_out/prof/pmc_$c.err
   echo "$c rc=$?"
 done
 F=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)

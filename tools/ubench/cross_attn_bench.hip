@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   };
   CrossAbsorbDesc d;
   d.q = fill((size_t)M * D, 0.6f); d.ldq = D;
-  d.E = fill(((size_t)crops * (npad + 64) + 64) * ED, 1.0f); d.tiled = getenv("CAB_TILED") ? 1 : 0; d.kv_rows = npad; d.n_keys = n_tok; d.enc_dim = ED;
+  d.E = fill(((size_t)crops * (npad + 64) + 64) * ED, 1.0f); d.kv_rows = npad; d.n_keys = n_tok; d.enc_dim = ED;
   d.wkt = fill((size_t)D * ED, 0.08f); d.wv = fill((size_t)D * ED, 0.04f);
   float* bv = nullptr;
   CK(hipMalloc((void**)&bv, D * 4));
