@@ -96,6 +96,17 @@ __device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __
   constexpr int NW = 2 * W, ROWB = ED * 2, KS = ED / 64, MT = ED / 32;
   const int g = lane >> 4;
     // ---- partial S^T[32 keys][16 heads] = E_tile[:, half] Qt[:, half]^T
+#ifdef CA_DMA_ONLY      // measurement aid (tools/ubench): the stream alone, 0 = burst after the barrier, 1 = + the exchange barrier
+    if (FEED) {
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) {
+        const int i = wave + j * NW;
+        if (NI % NW == 0 || i < NI) glds16(feed_src + dma_off[j], feed_dst + i * 1024);
+      }
+    }
+    if (CA_DMA_ONLY) __builtin_amdgcn_s_barrier();
+    return;
+#endif
     float4v s[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
     constexpr int EVERY = (KS / NPW) > 0 ? (KS / NPW) : 1;
     constexpr int AHEAD = KS < 4 ? KS : 4;
