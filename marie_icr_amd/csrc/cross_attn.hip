@@ -71,7 +71,12 @@ struct CrossArgs {
   int n_keys, heads;
 };
 
-constexpr int TK = 32;   // keys per tile
+#ifndef CA_TK
+#define CA_TK 32
+#endif
+constexpr int TK = CA_TK;   // keys per tile: 32 (two 16-key row tiles, K = 32 in the second product) or 16 (one, K = 16)
+static_assert(TK == 16 || TK == 32, "cross_attn key tile");
+constexpr int RT = TK / 16;
 // ring slots that fit beside the score-exchange buffer (2 W waves x 2 KiB) in 160 KiB of LDS
 constexpr int cross_slots(int ed, int w) {
   const int n = (160 * 1024 - 4 * w * 1024) / (TK * ed * 2);
@@ -110,18 +115,18 @@ __device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __
     float4v s[2] = {(float4v){0.f, 0.f, 0.f, 0.f}, (float4v){0.f, 0.f, 0.f, 0.f}};
     constexpr int EVERY = (KS / NPW) > 0 ? (KS / NPW) : 1;
     constexpr int AHEAD = KS < 4 ? KS : 4;
-    half8v a0[KS], a1[KS];
+    half8v a0[KS], a1[RT == 2 ? KS : 1];
 #pragma unroll
     for (int ks = 0; ks < AHEAD; ++ks) {
       a0[ks] = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2));
-      a1[ks] = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2) + 16 * ROWB);
+      if (RT == 2) a1[ks] = *(const half8v*)(sb + a_off[ks & 3] + 256 * (ks >> 2) + 16 * ROWB);
     }
     __builtin_amdgcn_sched_barrier(0);      // the scheduler sinks such reads back to their use (fewer live registers) unless fenced
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (ks + AHEAD < KS) {
         a0[ks + AHEAD] = *(const half8v*)(sb + a_off[(ks + AHEAD) & 3] + 256 * ((ks + AHEAD) >> 2));
-        a1[ks + AHEAD] = *(const half8v*)(sb + a_off[(ks + AHEAD) & 3] + 256 * ((ks + AHEAD) >> 2) + 16 * ROWB);
+        if (RT == 2) a1[ks + AHEAD] = *(const half8v*)(sb + a_off[(ks + AHEAD) & 3] + 256 * ((ks + AHEAD) >> 2) + 16 * ROWB);
       }
       // the DMA instructions of the tile that refills the slot freed at this tile's barrier go out now, as early as they may,
       // one per k-step (not in one burst: the CU's vector-memory queue drains a 1 KiB instruction every ~33 cycles and a wave
@@ -132,7 +137,7 @@ __device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __
       }
       __builtin_amdgcn_sched_barrier(0);    // reads of k-step ks + AHEAD | MFMAs of k-step ks: the order stays
       s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ks], qf[ks], s[0], 0, 0, 0);
-      s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], qf[ks], s[1], 0, 0, 0);
+      if (RT == 2) s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[RT == 2 ? ks : 0], qf[ks], s[1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (FEED) {
@@ -144,21 +149,22 @@ __device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __
     }
     // the other half's partial sums (same lane layout)
     xb[(wave * 2 + 0) * 64 + lane] = s[0];
-    xb[(wave * 2 + 1) * 64 + lane] = s[1];
+    if (RT == 2) xb[(wave * 2 + 1) * 64 + lane] = s[1];
     __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the LDS writes above
     __builtin_amdgcn_s_barrier();
     s[0] += xb[((wave ^ 1) * 2 + 0) * 64 + lane];
-    s[1] += xb[((wave ^ 1) * 2 + 1) * 64 + lane];
+    if (RT == 2) s[1] += xb[((wave ^ 1) * 2 + 1) * 64 + lane];
     // lane (n, g) holds head n, keys t*32 + 16 mt + 4 g + e.  Keys past the end: -inf.
     const int key0 = t * TK;
     if (key0 + TK > n_keys) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (key0 + 16 * mt + 4 * g + e >= n_keys) s[mt][e] = -INFINITY;
     }
-    float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+    if (RT == 2) mx = fmaxf(mx, fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (t == 0) {
@@ -170,9 +176,9 @@ __device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __
 #pragma unroll
       for (int i = 0; i < MT; ++i) acc[i] *= f;
     }
-    half8v pf;
+    half8v pf = (half8v){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float pe = __builtin_amdgcn_exp2f(s[mt][e] - mref);
@@ -181,22 +187,27 @@ __device__ __forceinline__ void cross_tile(const char* __restrict__ sb, char* __
       }
     // ---- Ct^T[half of ED][16 heads] += E_tile[:, half]^T P^T
     constexpr int TAHEAD = MT < 6 ? MT : 6;
-    half4v tlo[MT], thi[MT];
+    half4v tlo[MT], thi[RT == 2 ? MT : 1];
+    const half4v pf4 = __builtin_shufflevector(pf, pf, 0, 1, 2, 3);
 #pragma unroll
     for (int mt = 0; mt < TAHEAD; ++mt) {
       tlo[mt] = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3));
-      thi[mt] = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3) + 16 * ROWB);
+      if (RT == 2) thi[mt] = lds_tr16(sb + t_off[mt & 7] + 256 * (mt >> 3) + 16 * ROWB);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (mt + TAHEAD < MT) {
         tlo[mt + TAHEAD] = lds_tr16(sb + t_off[(mt + TAHEAD) & 7] + 256 * ((mt + TAHEAD) >> 3));
-        thi[mt + TAHEAD] = lds_tr16(sb + t_off[(mt + TAHEAD) & 7] + 256 * ((mt + TAHEAD) >> 3) + 16 * ROWB);
+        if (RT == 2) thi[mt + TAHEAD] = lds_tr16(sb + t_off[(mt + TAHEAD) & 7] + 256 * ((mt + TAHEAD) >> 3) + 16 * ROWB);
       }
       __builtin_amdgcn_sched_barrier(0);
-      const half8v a = __builtin_shufflevector(tlo[mt], thi[mt], 0, 1, 2, 3, 4, 5, 6, 7);
-      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf, acc[mt], 0, 0, 0);
+      if constexpr (RT == 2) {
+        const half8v a = __builtin_shufflevector(tlo[mt], thi[mt], 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf, acc[mt], 0, 0, 0);
+      } else {
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(tlo[mt], pf4, acc[mt], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -244,7 +244,15 @@ __global__ __launch_bounds__(256) void gemm_fourwave_kernel(tg::Args p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) {
+#ifdef FW_ASM_MFMA
+        // round 3: the accumulators pinned to AGPRs by the operand constraint — as the builtin compiles, hipcc moves them between the
+        // register classes around every phase (~400 v_accvgpr_mov per iteration, section 9 of profiles/r02/f_gemm_tile_budget.txt)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(b[j]), "v"(a[i]));
+#else
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+#endif
+      }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -285,6 +293,9 @@ __global__ __launch_bounds__(256) void gemm_fourwave_kernel(tg::Args p) {
   }
 
   // ---- epilogue: bias, f16, 16-byte stores straight from the (transposed) accumulators
+#ifdef FW_ASM_MFMA
+  asm volatile("s_nop 15\n s_nop 15" ::: "memory");      // the compiler does not know the asm above is an MFMA: no hazard slots of its own
+#endif
   const int row0 = mt * 256 + wr * 128 + frow, col0 = nt * 256 + wc * 128 + 8 * fg;
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
