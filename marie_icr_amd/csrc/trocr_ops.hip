@@ -260,6 +260,80 @@ __global__ __launch_bounds__(64 * DA_WAVES) void decode_attn_kernel(DecAttnArgs 
     }
 }
 
+// ---- self-attention of a decoder step, f16 (the history is short: <= max_len + 1 = 16 keys in the bench) ------------------------
+// One wave per HYPOTHESIS, eight heads at a time: lane = (head of the group, 16-byte chunk of its 64 dims), so a wave-instruction
+// reads 1 KiB of one key row (half of the 2 KiB a 1024-wide row holds), a score is a dot product over the 8 lanes of a head (three
+// DPP adds), and the soft-max and the weighted values of a head never leave its 8 lanes: no LDS, no barrier, no cross-group
+// reduction.  Keys go four at a time (online soft-max per chunk), their K and V rows requested together.  The generic kernel above
+// spends a wave, an LDS score buffer, two barriers and an MFMA with one live row of sixteen on every (hypothesis, head): 105 us per
+// launch of 7680 x 16 tasks against ~2 KB of history each.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8sa __attribute__((ext_vector_type(8)));
+template <int CTRL>
+__device__ __forceinline__ float sa_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sa_sum8(float v) {      // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+  v += sa_dpp<0xB1>(v);
+  v += sa_dpp<0x4E>(v);
+  v += sa_dpp<0x141>(v);
+  return v;
+}
+__global__ __launch_bounds__(256) void decode_self_attn_f16_kernel(DecAttnArgs p, int heads, int rows) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  const int hh = lane >> 3, c = lane & 7;
+  const int my_slot = lane < p.n_keys ? p.anc[(size_t)r * p.anc_ld + lane] : 0;      // n_keys <= 64: one past step per lane
+  const _Float16* K = (const _Float16*)p.k;
+  const _Float16* V = (const _Float16*)p.v;
+  for (int h0 = 0; h0 < heads; h0 += 8) {
+    const int col = (h0 + hh) * 64 + c * 8;
+    const half8sa q8 = *(const half8sa*)((const _Float16*)p.q + (size_t)r * p.ldq + col);
+    half2v q2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q2[j] = (half2v){q8[2 * j], q8[2 * j + 1]};
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    for (int s0 = 0; s0 < p.n_keys; s0 += 4) {
+      half8sa k8[4], v8[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = min(s0 + u, p.n_keys - 1);                                      // clamp: the extra keys of the last chunk get weight 0
+        const size_t row = ((size_t)s * p.slots + __builtin_amdgcn_readlane(my_slot, s)) * p.ldk + col;
+        k8[u] = *(const half8sa*)(K + row);
+        v8[u] = *(const half8sa*)(V + row);
+      }
+      float sc[4], cm = m;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d = __builtin_amdgcn_fdot2(q2[j], (half2v){k8[u][2 * j], k8[u][2 * j + 1]}, d, false);
+        sc[u] = s0 + u < p.n_keys ? sa_sum8(d) : -INFINITY;
+        cm = fmaxf(cm, sc[u]);
+      }
+      const float alpha = __expf(m - cm);          // m = -inf on the first chunk: exp(-inf) = 0, acc and l are 0 anyway
+      m = cm;
+      l *= alpha;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float pe = __expf(sc[u] - m);
+        l += pe;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(pe, (float)v8[u][j], acc[j]);
+      }
+    }
+    const float inv = 1.f / l;
+    half8sa o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)(acc[j] * inv);
+    *(half8sa*)((_Float16*)p.out + (size_t)r * p.ldo + col) = o;
+  }
+}
+
 // ---- beam candidates ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned okey(float f) {
   unsigned u = __float_as_uint(f);
@@ -450,6 +524,13 @@ int mhip_launch_decode_attention(mhip_ctx* ctx, int precision, const DecAttnDesc
   DecAttnArgs a;
   a.q = d.q; a.k = d.k; a.v = d.v; a.out = d.out; a.anc = d.anc; a.anc_ld = d.anc_ld; a.slots = d.slots;
   a.kv_rows = d.kv_rows; a.ldq = d.ldq; a.ldk = d.ldk; a.ldo = d.ldo; a.n_keys = d.n_keys; a.nq = d.nq;
+  static const bool generic_only = getenv("MARIE_HIP_GENERIC_SELF_ATTN") != nullptr;      // A/B aid
+  if (precision == MHIP_PREC_F16 && d.anc && d.nq == 1 && d.n_keys <= 64 && d.heads % 8 == 0 && !generic_only &&
+      d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldo % 8 == 0) {
+    PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL(decode_self_attn_f16_kernel, dim3((d.groups + 3) / 4), dim3(256), 0, ctx->stream, a, d.heads, d.groups));
+    CHECK_LAUNCH(ctx, "decode_self_attention");
+    return 0;
+  }
   const int tasks = d.heads * d.groups;
   dim3 grid((tasks + DA_WAVES - 1) / DA_WAVES), block(64 * DA_WAVES);
 #define DA_LAUNCH1(T, Q, K, A) PROF_LAUNCH(ctx, MHIP_K_DEC_OPS, hipLaunchKernelGGL((decode_attn_kernel<T, Q, K, A>), grid, block, 0, ctx->stream, a, d.heads, tasks))
