@@ -117,21 +117,36 @@ class OcrProcessor:
         by_line: Dict[int, list] = {}                       # the reference scans all words per line id; same order, one pass
         for word in words:
             by_line.setdefault(int(word["line"]), []).append(word)
+        # per line: the block around its boxes (merge_bboxes_as_block) and the mean confidence (np.average) — the same numpy
+        # reductions as the reference's per-line calls, run once per page over segments instead of 8 small calls per line
+        starts, order, confs = [], [], []
+        for line_numer in unique_line_ids:
+            group = by_line.get(int(line_numer), ())
+            if len(group) == 0:
+                raise Exception("Every word needs to be associated with a box")
+            starts.append(len(order))
+            for word in group:
+                order.append(indices[word["id"]])
+                confs.append(word["confidence"])
+        bsel = boxes[np.asarray(order)]
+        st = np.asarray(starts)
+        min_x = np.minimum.reduceat(bsel[:, 0], st)
+        min_y = np.minimum.reduceat(bsel[:, 1], st)
+        max_h = np.maximum.reduceat(bsel[:, 1] + bsel[:, 3], st) - min_y
+        max_w = np.maximum.reduceat(bsel[:, 0] + bsel[:, 2], st) - min_x
+        counts = np.diff(np.append(st, len(order)))
+        means = np.add.reduceat(np.asarray(confs, dtype=np.float64), st) / counts
         for i, line_numer in enumerate(unique_line_ids):
-            word_ids, box_picks, _w, _conf = [], [], [], []
+            word_ids, _w = [], []
             for word in by_line.get(int(line_numer), ()):
                 word["word_index"] = word_index
                 word_ids.append(word["id"])
-                box_picks.append(word["box"])
                 _w.append(word["text"])
-                _conf.append(word["confidence"])
                 aligned_words.append(word)
                 word_index += 1
-            if len(box_picks) == 0:
-                raise Exception("Every word needs to be associated with a box")
             line_results[i] = {"line": i + 1, "wordids": word_ids, "text": " ".join(_w),
-                               "bbox": merge_bboxes_as_block(np.array(box_picks)),
-                               "confidence": round(np.average(_conf), 4)}
+                               "bbox": [round(k, 6) for k in [min_x[i], min_y[i], max_w[i], max_h[i]]],
+                               "confidence": round(means[i], 4)}
         result = {"meta": meta, "words": aligned_words, "lines": line_results}
         if len(words) != len(aligned_words):
             raise Exception(f"Aligned words should match original words got: {len(aligned_words)}, {len(words)}")
