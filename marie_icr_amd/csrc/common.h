@@ -57,7 +57,18 @@ struct mhip_ctx {
   bool profiling = false;
   ProfSlot prof[MHIP_K_COUNT];
   std::vector<hipEvent_t> event_pool;
+  // pinned staging for small host temporaries that must reach the device without draining the stream (descriptor tables of a
+  // call): a ring of buffers, each guarded by the event of the copy that last read it (mhip_stage_h2d)
+  struct PinnedRing {
+    static constexpr int N = 4;
+    void* buf[N] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[N] = {0, 0, 0, 0};
+    hipEvent_t ev[N] = {nullptr, nullptr, nullptr, nullptr};
+    int next = 0;
+  } stage;
 };
+// dst_dev <- src_host (bytes) on ctx->stream through pinned memory; src_host may die when the call returns, the stream is not drained
+int mhip_stage_h2d(mhip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 
 int mhip_fail(mhip_ctx* ctx, int code, const char* fmt, ...);
 // Teardown: wait for the device, not for ctx->stream — the caller's stream (a torch stream handed in by mhip_set_stream) may

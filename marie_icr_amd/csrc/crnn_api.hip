@@ -58,9 +58,33 @@ extern "C" int mhip_destroy(mhip_ctx* ctx) {
       (void)hipEventDestroy(p.second);
     }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < mhip_ctx::PinnedRing::N; ++i) {
+    if (ctx->stage.ev[i]) (void)hipEventDestroy(ctx->stage.ev[i]);
+    if (ctx->stage.buf[i]) (void)hipHostFree(ctx->stage.buf[i]);
+  }
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->zeros) (void)hipFree(ctx->zeros);
   delete ctx;
+  return MHIP_OK;
+}
+
+int mhip_stage_h2d(mhip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!bytes) return MHIP_OK;
+  mhip_ctx::PinnedRing& r = ctx->stage;
+  const int i = r.next;
+  r.next = (i + 1) % mhip_ctx::PinnedRing::N;
+  if (r.ev[i]) MHIP_HIP(ctx, hipEventSynchronize(r.ev[i]));          // the copy that last read this buffer (four calls ago) is done
+  else MHIP_HIP(ctx, hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+  if (bytes > r.cap[i]) {
+    if (r.buf[i]) (void)hipHostFree(r.buf[i]);
+    r.buf[i] = nullptr; r.cap[i] = 0;
+    const size_t cap = std::max<size_t>(bytes, 64 * 1024);
+    MHIP_HIP(ctx, hipHostMalloc(&r.buf[i], cap, hipHostMallocDefault));
+    r.cap[i] = cap;
+  }
+  memcpy(r.buf[i], src_host, bytes);
+  MHIP_HIP(ctx, hipMemcpyAsync(dst_dev, r.buf[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+  MHIP_HIP(ctx, hipEventRecord(r.ev[i], ctx->stream));
   return MHIP_OK;
 }
 

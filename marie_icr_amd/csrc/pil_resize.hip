@@ -260,8 +260,12 @@ int mhip_pil_resize_fragments(mhip_ctx* ctx, const uint8_t* base_dev, const mhip
   int* kkx = (int*)p; p += al((size_t)n * dw * kx * 4);
   int* by = (int*)p; p += al((size_t)n * dh * 8);
   int* kky = (int*)p;
-  MHIP_HIP(ctx, hipMemcpyAsync(dfr, fr.data(), n * sizeof(FragDev), hipMemcpyHostToDevice, ctx->stream));
-  MHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // fr is a host temporary
+  // fr is a host temporary: through pinned staging, without draining the stream (the engine encodes page batches back to back;
+  // a drain here left the GPU idle while the host prepared the next batch: ~12 ms per 8 pages)
+  {
+    const int rc = mhip_stage_h2d(ctx, dfr, fr.data(), n * sizeof(FragDev));
+    if (rc) return rc;
+  }
   PROF_LAUNCH(ctx, MHIP_K_IMAGE_OPS, {
     hipLaunchKernelGGL(pil_coeffs_batch_kernel, dim3((dw + 255) / 256, n), dim3(256), 0, ctx->stream, dfr, 0, dw, filter, kx, bx, kkx);
     hipLaunchKernelGGL(pil_coeffs_batch_kernel, dim3((dh + 255) / 256, n), dim3(256), 0, ctx->stream, dfr, 1, dh, filter, ky, by, kky);
