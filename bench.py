@@ -52,6 +52,7 @@ plus the reference's numpy post-processing restated) on rank 0's host cores on a
 from __future__ import annotations
 
 import argparse
+import functools
 import json
 import os
 import sys
@@ -821,6 +822,7 @@ def run_engine_api(args, torch, det, rec, ctxs, streams, host_pages, gt):
         spans = []          # (what, pages, start, end) of every processor call: the timeline of the last extract()
 
         def timed(fn, key):
+            @functools.wraps(fn)          # the engine looks at the signature (copy_fragments)
             def wrapper(*a, **k):
                 t = time.perf_counter()
                 try:
