@@ -122,7 +122,10 @@ def test_encoder_per_batch_decoder_once_equals_one_call(ctx, case, precision):
 
     host = [rng.integers(0, 256, size=(int(h), int(w), 3)).astype(np.uint8) for h, w in ((40, 130), (25, 300), (60, 61), (33, 512))]
     p = TrOcrProcessor(state=st, config=_cfg(ctx), precision=precision, ctx=ctx)
-    batches = [windows(boxes[:2]), FragmentList(host[:3]), windows(boxes[2:]), FragmentList(host[3:])]
+    # six batches: more than the four buffers of the context's pinned staging ring (every batch's descriptor table goes through it
+    # without draining the stream)
+    batches = [windows(boxes[:2]), FragmentList(host[:3]), windows(boxes[2:3]), FragmentList(host[3:]), windows(boxes[3:4]),
+               windows(boxes[4:])]
     flat = [f for b in batches for f in b]
     ref = p.recognize_from_fragments(FragmentList(flat))
     shape = page.shape
@@ -132,16 +135,17 @@ def test_encoder_per_batch_decoder_once_equals_one_call(ctx, case, precision):
         p.recognize_pages_add([(page, [[0, 0, 1, 1]] * len(batches[0]), batches[0], [1] * len(batches[0]))])
         p.recognize_pages_add([(page, [], [], []),                                              # a blank page in the middle
                                (page, [[0, 0, 1, 1]] * len(batches[1]), batches[1], [1] * len(batches[1]))])
-        p.recognize_pages_add([(page, [[0, 0, 1, 1]] * len(b), b, list(range(1, len(b) + 1))) for b in batches[2:]])
+        for b in batches[2:]:
+            p.recognize_pages_add([(page, [[0, 0, 1, 1]] * len(b), b, list(range(1, len(b) + 1)))])
         out = p.recognize_pages_finish()
-        assert len(out) == 5
+        assert len(out) == 7
         got = [(w["text"], w["confidence"]) for res, _ in out for w in sorted(res["words"], key=lambda w: w["id"])]
         assert out[1][0]["words"] == [] and out[1][0]["meta"]["imageSize"] == {"width": shape[1], "height": shape[0]}
         want = [(r["text"], round(r["confidence"], 3)) for r in ref]
         assert sorted(got) == sorted(want)
         # per page: the page's own fragments, in order
         k = 0
-        for j, b in zip((0, 2, 3, 4), batches):
+        for j, b in zip((0, 2, 3, 4, 5, 6), batches):
             words = sorted(out[j][0]["words"], key=lambda w: w["id"])
             assert [w["text"] for w in words] == [r["text"] for r in ref[k:k + len(b)]]
             k += len(b)
