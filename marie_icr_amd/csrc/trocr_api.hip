@@ -92,7 +92,11 @@ extern "C" int mhip_trocr_create(mhip_ctx* ctx, int precision, const mhip_trocr_
   a.take("pos", (size_t)(c.max_positions + c.pad + 1) * D * 4);
   a.take("lne_g", D * 4); a.take("lne_b", D * 4);
   for (int l = 0; l < c.dec_layers; ++l) {
-    for (const char* n : {"sa_q", "sa_k", "sa_v", "sa_o", "ca_q", "ca_o"}) { a.take(lay(l, n) + "_w", D * D * es); a.take(lay(l, n) + "_b", D * 4); }
+    // the three self-attention input projections sit back to back — one [3 D][D] weight and one [3 D] bias for a single GEMM per
+    // layer and step (q | k | v of a step are one row of the history, below)
+    for (const char* n : {"sa_q", "sa_k", "sa_v"}) a.take(lay(l, n) + "_w", D * D * es);
+    for (const char* n : {"sa_q", "sa_k", "sa_v"}) a.take(lay(l, n) + "_b", D * 4);
+    for (const char* n : {"sa_o", "ca_q", "ca_o"}) { a.take(lay(l, n) + "_w", D * D * es); a.take(lay(l, n) + "_b", D * 4); }
     // absorbed encoder-attention: W_k lives only as ca_kt and b_k drops out of the soft-max — no ca_k slots in the arena
     for (const char* n : {"ca_k", "ca_v"}) {
       if (m->absorb && !strcmp(n, "ca_k")) continue;
@@ -254,7 +258,7 @@ static size_t trocr_ws_bytes(const mhip_trocr* m, int n) {
   size_t b = vit_workspace_bytes(m->vit, n, vg);
   if (m->absorb) b += 2 * M * 16 * (size_t)c.enc_dim * 2 + 512;      // absorbed queries / contexts
   else b += 2 * (size_t)c.dec_layers * n * vg.npad * D * es;          // cross K / V
-  b += 2 * (size_t)c.dec_layers * (ML + 1) * M * D * es;              // self K / V history
+  b += 3 * (size_t)c.dec_layers * (ML + 1) * M * D * es;              // self q | k | v history
   b += M * D * 4 + 3 * M * D * es + M * c.dec_ffn * es + M * ldv * 4; // x, xt, q, ao, hidden, logits
   b += 2 * M * (ML + 2) * 4 + (size_t)n * 2 * c.beam * 12 + (size_t)vg.n_tok * c.enc_dim * 4 + (size_t)c.vocab * 4 + 4096;
   b += mhip_beam_state_bytes(n, c.beam, (int)ML) + (size_t)n * (ML + 3) * 4 + 1024;   // generator state + device copies of the outputs
@@ -330,9 +334,8 @@ static int trocr_decode(mhip_trocr* m, Carver& ws, const char* enc_tokens, const
   // detector of the next page batch) runs underneath it
   if (m->decode_gate && (rc = mhip_gate_signal(m->decode_gate, ctx))) return rc;
   // ---- decoder state ------------------------------------------------------------------------------------------------
-  const size_t hist_s = (size_t)M * D * es;                  // one step of one layer
-  char* hk = ws.take((size_t)L * (ML + 1) * hist_s);
-  char* hv = ws.take((size_t)L * (ML + 1) * hist_s);
+  const size_t hist_s = (size_t)M * 3 * D * es;              // one step of one layer: rows of q | k | v
+  char* hqkv = ws.take((size_t)L * (ML + 1) * hist_s);
   float* x = ws.take<float>((size_t)M * D * 4);
   char* xt = ws.take((size_t)M * D * es);
   char* qb = ws.take((size_t)M * D * es);
@@ -368,15 +371,14 @@ static int trocr_decode(mhip_trocr* m, Carver& ws, const char* enc_tokens, const
     const float* pos_row = a.d<float>("pos") + (size_t)(c.pad + step + 1) * D;
     if ((rc = mhip_launch_embed_step(ctx, prec, bs.last_tok, a.d("emb"), pos_row, c.embed_scale, a.d<float>("lne_g"), a.d<float>("lne_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
     for (int l = 0; l < L; ++l) {
-      char* kl = hk + ((size_t)l * (ML + 1)) * hist_s;
-      char* vl = hv + ((size_t)l * (ML + 1)) * hist_s;
-      // self-attention over the hypothesis' own history (post-LN residual block)
-      if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "sa_q") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "sa_q") + "_b"), qb, ACT_NONE, 0))) return rc;
-      if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "sa_k") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "sa_k") + "_b"), kl + (size_t)step * hist_s, ACT_NONE, 0))) return rc;
-      if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "sa_v") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "sa_v") + "_b"), vl + (size_t)step * hist_s, ACT_NONE, 0))) return rc;
+      char* hl = hqkv + ((size_t)l * (ML + 1)) * hist_s;
+      // self-attention over the hypothesis' own history (post-LN residual block): q | k | v of this step in ONE GEMM (the three
+      // weights are adjacent in the arena), written as one row of the history
+      if ((rc = mhip_gemm(ctx, prec, xt, a.d(lay(l, "sa_q") + "_w"), M, 3 * D, D, nullptr, a.d<float>(lay(l, "sa_q") + "_b"), hl + (size_t)step * hist_s, ACT_NONE, 0))) return rc;
       DecAttnDesc sa;
-      sa.q = qb; sa.k = kl; sa.v = vl; sa.out = ao; sa.anc = anc[cur]; sa.anc_ld = anc_ld; sa.slots = M;
-      sa.ldq = sa.ldk = sa.ldo = D; sa.heads = c.dec_heads; sa.groups = M; sa.nq = 1; sa.n_keys = step + 1;
+      sa.q = hl + (size_t)step * hist_s; sa.k = hl + (size_t)D * es; sa.v = hl + (size_t)2 * D * es; sa.out = ao;
+      sa.anc = anc[cur]; sa.anc_ld = anc_ld; sa.slots = M;
+      sa.ldq = sa.ldk = 3 * D; sa.ldo = D; sa.heads = c.dec_heads; sa.groups = M; sa.nq = 1; sa.n_keys = step + 1;
       if ((rc = mhip_launch_decode_attention(ctx, prec, sa))) return rc;
       if ((rc = mhip_gemm(ctx, prec, ao, a.d(lay(l, "sa_o") + "_w"), M, D, D, nullptr, a.d<float>(lay(l, "sa_o") + "_b"), x, ACT_NONE, 1, x))) return rc;
       if ((rc = mhip_launch_layernorm2(ctx, prec, x, a.d<float>(lay(l, "sa_ln") + "_g"), a.d<float>(lay(l, "sa_ln") + "_b"), x, xt, M, D, DEC_LN_EPS))) return rc;
